@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline measurement on MI355X: per-op wall time and effective HBM GB/s
+(BASELINE.json `metric`) for the scatter/gather hot path.
+
+One "step" = one cold call of the hot path on one batch of synthetic input:
+    torch_scatter.scatter_add(src, index, dim=0, dim_size=N)    (reference: op_bm_scripts/benchmark_scatter_add.py:15-19)
+with a 1-D row index — plan build (radix sort of the index) + segment reduce, nothing cached.
+Workload at N=1 is BASELINE config 2 (configs[1]): N=10M destinations, E=50M source rows, D=128 fp32.
+With --gpus G every rank holds its own E=50M rows with destinations over G*10M rows, reduces locally
+into a partial [G*10M, D] buffer and ONE RCCL reduce-scatter hands each rank the slab it owns (weak
+scaling).
+
+`value` = algorithmic bytes (E*D*s + E*8 + N*D*s per step, x ranks) / wall time, inputs
+already resident in HBM. The JSON line also carries `roofline` (dominant kernel = the segment-reduce
+launch, timed with events on the launch stream), `cpu_baseline` (the C oracle port on a bounded sample,
+host cores of this box) and per-op numbers for the other config-2 ops.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "gnn-ops-benchmark_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (N per GPU, E per GPU, D, dtype)
+    "c2": (10_000_000, 50_000_000, 128, "f32"),     # BASELINE configs[1]
+    "c5": (10_000_000, 100_000_000, 128, "f32"),    # BASELINE configs[4] per-GPU share (N=80M,E=800M at 8 GPUs)
+    "c1": (100_000, 500_000, 64, "f32"),            # BASELINE configs[0] shape (plumbing)
+    "tiny": (20_000, 100_000, 128, "f32"),
+}
+
+
+def algorithmic_bytes(op, N, E, D, s=4):
+    """SURVEY.md §8(d) per-call figures."""
+    if op in ("scatter_add", "scatter_mean"):
+        return E * D * s + E * 8 + N * D * s
+    if op in ("scatter_min", "scatter_max"):
+        return E * D * s + E * 8 + N * D * s + N * D * 8
+    if op == "index_select":
+        return N * D * s + E * 8 + E * D * s
+    if op == "index_add_":
+        return E * D * s + E * 8 + 2 * N * D * s
+    raise KeyError(op)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-ops", action="store_true", help="skip the per-op table (scatter_min/max/mean, index_select, index_add_)")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import gnnops
+
+    lib = gnnops.load_library()  # fails loudly if the HIP extension is missing
+    gnnops.set_plan_cache(False)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    Nloc, E, D, _ = WORKLOADS[args.workload]
+    Ntot = Nloc * world
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    src = torch.rand(E, D, generator=gen, device=dev, dtype=torch.float32)
+    index = torch.randint(0, Ntot, (E,), generator=gen, device=dev, dtype=torch.int64)
+    slab = torch.empty(Nloc, D, device=dev, dtype=torch.float32) if world > 1 else None
+
+    def step():
+        if world == 1:
+            return gnnops.scatter_add(src, index, dim=0, dim_size=Ntot)
+        from gnnops.dist import sharded_scatter
+
+        return sharded_scatter(src, index, Ntot, "sum", out_slab=slab)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    job_bytes = world * algorithmic_bytes("scatter_add", Nloc, E, D)
+    value = job_bytes / (elapsed / args.steps) / 1e9
+
+    result = {
+        "metric": "scatter_add effective HBM GB/s (algorithmic bytes / wall time, cold: plan build + segment reduce per call)",
+        "value": round(value, 1),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (uniform random src, uniform random unsorted int64 row index, device RNG seed 42)",
+        "config": {
+            "workload": f"{args.workload}: torch_scatter.scatter_add(src[E,D], index[E], dim=0, dim_size=N), "
+                        f"N={Ntot} E={E * world} D={D} fp32, layout R" + ("" if world == 1 else
+                        f"; per GPU E={E}, owned rows={Nloc}, one RCCL reduce-scatter of the [N,D] partials"),
+            "algorithmic_GB_per_step": round(job_bytes / 1e9, 3),
+            "pct_of_hbm_peak": round(100 * value / (HBM_PEAK_GBS * world), 2),
+        },
+    }
+
+    if rank == 0 and world == 1:
+        result["roofline"] = roofline_leg(torch, gnnops, lib, src, index, Ntot, E, D, args.steps)
+        result["warm"] = warm_leg(torch, gnnops, src, index, Ntot, E, D, args.steps)
+        if not args.no_extra_ops:
+            result["ops"] = extra_ops(torch, gnnops, src, index, Ntot, E, D)
+        if not args.no_cpu_baseline:
+            del out
+            result["cpu_baseline"] = cpu_baseline_leg(D)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _event_ms(torch, fn, iters):
+    """Average device time of fn() over `iters` launches, events on the current (= launch) stream."""
+    fn()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters):
+    """Dominant kernel: seg_rows_kernel<float, SUM> (one launch of gnnops_segment_reduce over a prebuilt plan)."""
+    from gnnops import _lib
+    from gnnops.ops import _stream
+
+    plan = gnnops.Plan(index, N)
+    out = torch.empty(N, D, device=src.device, dtype=torch.float32)
+
+    def launch():
+        rc = lib.gnnops_segment_reduce(src.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(), out.data_ptr(), None,
+                                       1, E, D, N, _lib.F32, _lib.SUM, 0, _stream())
+        _lib.check(rc, "segment_reduce")
+
+    ms = _event_ms(torch, launch, max(iters, 5))
+    plan_ms = _event_ms(torch, lambda: gnnops.Plan(index, N), 3)
+    alg = algorithmic_bytes("scatter_add", N, E, D)
+    achieved = alg / (ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("seg_rows_kernel_f32_sum", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {
+        "kernel": "seg_rows_kernel<float,SUM> (gnnops_segment_reduce)",
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "kernel_ms": round(ms, 4),
+        "algorithmic_bytes_per_launch": alg,
+        "plan_build_ms": round(plan_ms, 4),
+    }
+
+
+def warm_leg(torch, gnnops, src, index, N, E, D, iters):
+    """Same op with the plan reused across calls (static edge_index): what a GNN layer loop sees."""
+    plan = gnnops.Plan(index, N)
+    ms = _event_ms(torch, lambda: gnnops.scatter_add(src, plan, dim=0), max(iters, 5))
+    alg = algorithmic_bytes("scatter_add", N, E, D)
+    return {"ms": round(ms, 4), "GBps": round(alg / ms / 1e6, 1), "pct_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS * 100, 2)}
+
+
+def extra_ops(torch, gnnops, src, index, N, E, D):
+    """The other config-2 ops, cold (no cached plan) and, where a plan applies, warm."""
+    res = {}
+    plan = gnnops.Plan(index, N)
+
+    def rec(name, fn, alg_op, iters=5):
+        ms = _event_ms(torch, fn, iters)
+        alg = algorithmic_bytes(alg_op, N, E, D)
+        res[name] = {"ms": round(ms, 4), "GBps": round(alg / ms / 1e6, 1),
+                     "pct_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS * 100, 2)}
+
+    rec("scatter_mean_cold", lambda: gnnops.scatter_mean(src, index, 0, dim_size=N), "scatter_mean")
+    rec("scatter_min_cold", lambda: gnnops.scatter_min(src, index, 0, dim_size=N), "scatter_min")
+    rec("scatter_max_cold", lambda: gnnops.scatter_max(src, index, 0, dim_size=N), "scatter_max")
+    rec("scatter_min_warm", lambda: gnnops.scatter_min(src, plan, 0), "scatter_min")
+    acc = torch.zeros(N, D, device=src.device)
+    rec("index_add__cold", lambda: gnnops.index_add_(acc, 0, index, src), "index_add_")
+    rec("index_add__warm", lambda: gnnops.index_add_(acc, 0, plan, src), "index_add_")
+    del acc
+    table = torch.rand(N, D, device=src.device)
+    rec("index_select_pull", lambda: gnnops.index_select(table, 0, index), "index_select")
+    rec("index_select_push_warm", lambda: gnnops.index_select(table, 0, index, plan=plan), "index_select")
+    rec("index_select_push_cold", lambda: gnnops.index_select(table, 0, index, plan=gnnops.Plan(index, N)), "index_select")
+    return res
+
+
+def cpu_baseline_leg(D):
+    """The C oracle port (one core) on a bounded sample of the same workload: N=1M, E=5M, D as configured."""
+    import numpy as np
+
+    from oracle import oracle
+
+    oracle.lib()
+    Ns, Es = 1_000_000, 5_000_000
+    rng = np.random.default_rng(42)
+    src = rng.random((Es, D), dtype=np.float32)
+    idx = rng.integers(0, Ns, Es, dtype=np.int64)
+    oracle.scatter_add_rows_f32(src[:1000], idx[:1000] % 10, 10)  # page in the library
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        oracle.scatter_add_rows_f32(src, idx, Ns)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 20:
+            break
+    alg = algorithmic_bytes("scatter_add", Ns, Es, D)
+    return {
+        "value": round(alg * reps / dt / 1e9, 3),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle/gnnops_oracle.c ora_scatter_add_rows_f32, N={Ns} E={Es} D={D} fp32 (1/10 of config 2), "
+                  f"{reps} passes in {dt:.1f} s on one of {os.cpu_count()} host cores",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+// Shared device/host helpers for the gfx950 kernels. CDNA4 only: 64-lane waves are hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gnnops.h"
+
+#define GNNOPS_WAVE 64
+
+// ---- error plumbing (thread-local message, C ABI never throws) ----
+void gnnops_set_error(const char* fmt, ...);
+int gnnops_check_launch(const char* what);
+
+#define GNNOPS_REQUIRE(cond, code, ...)            \
+    do {                                           \
+        if (!(cond)) {                             \
+            gnnops_set_error(__VA_ARGS__);         \
+            return (code);                         \
+        }                                          \
+    } while (0)
+
+static inline int64_t gnnops_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Memory-bound launches: enough workgroups to fill 256 CUs several times over, grid-stride the rest
+// (cdna_hip_programming.md Guideline 11).
+static inline int gnnops_grid_cap(int64_t want, int64_t cap = 256 * 16) {
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+// ---- 16-byte vector type used for every wide global access ----
+struct __attribute__((aligned(16))) u32x4 { uint32_t x, y, z, w; };
+
+// ---- element traits: fp32 compute for every storage type ----
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;  // elements per 16 B
+    __device__ static inline float load(const float* p) { return *p; }
+    __device__ static inline void store(float* p, float v) { *p = v; }
+    __device__ static inline void unpack(const u32x4& r, float* f) {
+        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y);
+        f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+    }
+    __device__ static inline u32x4 pack(const float* f) {
+        u32x4 r; r.x = __float_as_uint(f[0]); r.y = __float_as_uint(f[1]);
+        r.z = __float_as_uint(f[2]); r.w = __float_as_uint(f[3]); return r;
+    }
+};
+template <> struct Elem<__half> {
+    static constexpr int VEC = 8;
+    __device__ static inline float load(const __half* p) { return __half2float(*p); }
+    __device__ static inline void store(__half* p, float v) { *p = __float2half(v); }
+    __device__ static inline void unpack(const u32x4& r, float* f) {
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __half2 h = *reinterpret_cast<const __half2*>(&w[i]);
+            float2 t = __half22float2(h);
+            f[2 * i] = t.x; f[2 * i + 1] = t.y;
+        }
+    }
+    __device__ static inline u32x4 pack(const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __half2 h = __floats2half2_rn(f[2 * i], f[2 * i + 1]);
+            w[i] = *reinterpret_cast<uint32_t*>(&h);
+        }
+        u32x4 r; r.x = w[0]; r.y = w[1]; r.z = w[2]; r.w = w[3]; return r;
+    }
+};
+template <> struct Elem<__hip_bfloat16> {
+    static constexpr int VEC = 8;
+    __device__ static inline float load(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+    __device__ static inline void store(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+    __device__ static inline void unpack(const u32x4& r, float* f) {
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // bf16 -> f32 is a 16-bit shift
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static inline u32x4 pack(const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __hip_bfloat16 lo = __float2bfloat16(f[2 * i]);
+            __hip_bfloat16 hi = __float2bfloat16(f[2 * i + 1]);
+            uint16_t l = *reinterpret_cast<uint16_t*>(&lo);
+            uint16_t h = *reinterpret_cast<uint16_t*>(&hi);
+            w[i] = (uint32_t)l | ((uint32_t)h << 16);
+        }
+        u32x4 r; r.x = w[0]; r.y = w[1]; r.z = w[2]; r.w = w[3]; return r;
+    }
+};
+
+// ---- reduce functors (compute in fp32) ----
+template <int R> struct Red;
+template <> struct Red<GNNOPS_SUM> {
+    __device__ static inline float identity() { return 0.f; }
+    __device__ static inline float apply(float a, float v) { return a + v; }
+};
+template <> struct Red<GNNOPS_MEAN> : Red<GNNOPS_SUM> {};
+template <> struct Red<GNNOPS_MUL> {
+    __device__ static inline float identity() { return 1.f; }
+    __device__ static inline float apply(float a, float v) { return a * v; }
+};
+template <> struct Red<GNNOPS_MIN> {
+    __device__ static inline float identity() { return __builtin_huge_valf(); }
+    __device__ static inline bool better(float v, float a) { return v < a; }
+};
+template <> struct Red<GNNOPS_MAX> {
+    __device__ static inline float identity() { return -__builtin_huge_valf(); }
+    __device__ static inline bool better(float v, float a) { return v > a; }
+};
+
+__device__ static inline int lane_id() { return threadIdx.x & 63; }

@@ -1,0 +1,300 @@
+// gather.hip — row/element gathers: torch.index_select, torch.gather, and the fused
+// index_select(...).sum(). Reference call sites: op_bm_scripts/benchmark_native_index_select.py:12-15,
+// benchmark_native_gather.py:14-17, benchmark_fused_index_select_reduce.py:12-20.
+//
+// All HBM-bound byte movers: 16-B lane accesses along the feature dimension, several rows in flight
+// per lane group to cover the dependent index -> row latency. No MFMA here by design.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_IN_FLIGHT = 4;
+
+// Pull form. Row = rowbytes bytes (multiple of 16), G = 2^gshift lanes per row, chunks of G*16 bytes.
+// item = ((b*chunks + c) * E + e)
+__global__ __launch_bounds__(256) void select_rows_kernel(const char* __restrict__ in, const int64_t* __restrict__ index,
+                                                          char* __restrict__ out, int64_t B, int64_t N, int64_t E,
+                                                          int64_t rowbytes, int gshift, int chunks) {
+    const int G = 1 << gshift;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
+    const int gl = (int)(gtid & (G - 1));
+    const int64_t items = B * (int64_t)chunks * E;
+    for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * ROWS_IN_FLIGHT) {
+        int64_t srcoff[ROWS_IN_FLIGHT], dstoff[ROWS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+            const int64_t item = item0 + (int64_t)u * ngroups;
+            srcoff[u] = -1;
+            if (item < items) {
+                const int64_t e = item % E;
+                const int64_t bc = item / E;
+                const int c = (int)(bc % chunks);
+                const int64_t b = bc / chunks;
+                const int64_t colb = ((int64_t)c * G + gl) * 16;
+                if (colb < rowbytes) {
+                    const int64_t n = index[e];
+                    srcoff[u] = (b * N + n) * rowbytes + colb;
+                    dstoff[u] = (b * E + e) * rowbytes + colb;
+                }
+            }
+        }
+        u32x4 v[ROWS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
+            if (srcoff[u] >= 0) v[u] = *reinterpret_cast<const u32x4*>(in + srcoff[u]);
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
+            if (srcoff[u] >= 0) *reinterpret_cast<u32x4*>(out + dstoff[u]) = v[u];
+    }
+}
+
+// Push form over a plan: item = ((b*chunks + c) * N + n); the input row is loaded once and stored to
+// every output row of its segment.
+__global__ __launch_bounds__(256) void select_rows_push_kernel(const char* __restrict__ in,
+                                                               const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ perm, char* __restrict__ out,
+                                                               int64_t B, int64_t N, int64_t E, int64_t rowbytes,
+                                                               int gshift, int chunks) {
+    const int G = 1 << gshift;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
+    const int gl = (int)(gtid & (G - 1));
+    const int64_t items = B * (int64_t)chunks * N;
+    for (int64_t item = gtid >> gshift; item < items; item += ngroups) {
+        const int64_t n = item % N;
+        const int64_t bc = item / N;
+        const int c = (int)(bc % chunks);
+        const int64_t b = bc / chunks;
+        const int64_t colb = ((int64_t)c * G + gl) * 16;
+        if (colb >= rowbytes) continue;
+        const int32_t beg = rowptr[n], end = rowptr[n + 1];
+        if (beg == end) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(in + (b * N + n) * rowbytes + colb);
+        char* outb = out + (b * E) * rowbytes + colb;
+        for (int32_t j = beg; j < end; ++j) {
+            const int64_t e = perm[j];
+            *reinterpret_cast<u32x4*>(outb + e * rowbytes) = v;
+        }
+    }
+}
+
+// Element forms (any K / alignment). index_select: index[e]; gather: index[b,e,k].
+template <typename U, bool FULL_INDEX>
+__global__ __launch_bounds__(256) void select_elems_kernel(const U* __restrict__ in, const int64_t* __restrict__ index,
+                                                           U* __restrict__ out, int64_t B, int64_t N, int64_t K,
+                                                           int64_t E) {
+    const int64_t total = B * E * K;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = o % K;
+        const int64_t be = o / K;
+        const int64_t e = be % E;
+        const int64_t b = be / E;
+        const int64_t n = FULL_INDEX ? index[o] : index[e];
+        out[o] = in[(b * N + n) * K + k];
+    }
+}
+
+// ---- fused index_select + sum ----
+constexpr int FUSED_BLOCKS = 256 * 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void select_sum_rows_kernel(const T* __restrict__ in, const int64_t* __restrict__ index,
+                                                              float* __restrict__ partial, int64_t B, int64_t N,
+                                                              int64_t K, int64_t E, int gshift, int chunks) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float s_part[4];
+    const int G = 1 << gshift;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
+    const int gl = (int)(gtid & (G - 1));
+    const int64_t items = B * (int64_t)chunks * E;
+    float acc = 0.f;
+    for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * ROWS_IN_FLIGHT) {
+        const T* p[ROWS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+            const int64_t item = item0 + (int64_t)u * ngroups;
+            p[u] = nullptr;
+            if (item < items) {
+                const int64_t e = item % E;
+                const int64_t bc = item / E;
+                const int c = (int)(bc % chunks);
+                const int64_t b = bc / chunks;
+                const int64_t col = ((int64_t)c * G + gl) * VEC;
+                if (col < K) p[u] = in + (b * N + index[e]) * K + col;
+            }
+        }
+        u32x4 v[ROWS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
+            if (p[u]) v[u] = *reinterpret_cast<const u32x4*>(p[u]);
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+            if (p[u]) {
+                float f[VEC];
+                Elem<T>::unpack(v[u], f);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc += f[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void select_sum_elems_kernel(const T* __restrict__ in, const int64_t* __restrict__ index,
+                                                               float* __restrict__ partial, int64_t B, int64_t N,
+                                                               int64_t K, int64_t E) {
+    __shared__ float s_part[4];
+    const int64_t total = B * E * K;
+    float acc = 0.f;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = o % K;
+        const int64_t be = o / K;
+        const int64_t e = be % E;
+        const int64_t b = be / E;
+        acc += Elem<T>::load(in + (b * N + index[e]) * K + k);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+// Fixed-order combine of the block partials (one block), so the result is run-to-run reproducible.
+__global__ __launch_bounds__(256) void combine_partials_kernel(const float* __restrict__ partial, int n,
+                                                               float* __restrict__ out) {
+    __shared__ float s_part[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+struct RowGeom { int gshift; int chunks; };
+inline RowGeom row_geom(int64_t vecs) {
+    RowGeom g{0, 1};
+    while ((1 << g.gshift) < vecs && g.gshift < 6) ++g.gshift;
+    g.chunks = (int)gnnops_cdiv(vecs, (int64_t)1 << g.gshift);
+    return g;
+}
+
+template <typename T>
+int launch_select_sum(const void* input, const int64_t* index, float* d_sum, int64_t B, int64_t N, int64_t K,
+                      int64_t E, float* partial, hipStream_t stream) {
+    constexpr int VEC = Elem<T>::VEC;
+    int grid;
+    if (K % VEC == 0 && (uintptr_t)input % 16 == 0) {
+        RowGeom g = row_geom(K / VEC);
+        const int64_t items = B * g.chunks * E;
+        grid = gnnops_grid_cap(gnnops_cdiv(items, (256 >> g.gshift) * ROWS_IN_FLIGHT), FUSED_BLOCKS);
+        hipLaunchKernelGGL((select_sum_rows_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)input, index,
+                           partial, B, N, K, E, g.gshift, g.chunks);
+    } else {
+        grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256 * 4), FUSED_BLOCKS);
+        hipLaunchKernelGGL((select_sum_elems_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)input, index,
+                           partial, B, N, K, E);
+    }
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(1), dim3(256), 0, stream, partial, grid, d_sum);
+    return gnnops_check_launch("fused_index_select_sum");
+}
+
+}  // namespace
+
+extern "C" int gnnops_index_select(const void* input, const int64_t* index, void* out, int64_t B, int64_t N,
+                                   int64_t K, int64_t E, int elem_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "index_select: negative size");
+    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "index_select: elem_bytes %d", elem_bytes);
+    if (B * E * K == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(input && index && out, GNNOPS_EINVAL, "index_select: null pointer");
+    const int64_t rowbytes = K * elem_bytes;
+    if (rowbytes % 16 == 0 && (uintptr_t)input % 16 == 0 && (uintptr_t)out % 16 == 0) {
+        RowGeom g = row_geom(rowbytes / 16);
+        const int64_t items = B * g.chunks * E;
+        int grid = gnnops_grid_cap(gnnops_cdiv(items, (256 >> g.gshift) * ROWS_IN_FLIGHT), 256 * 32);
+        hipLaunchKernelGGL(select_rows_kernel, dim3(grid), dim3(256), 0, stream, (const char*)input, index, (char*)out,
+                           B, N, E, rowbytes, g.gshift, g.chunks);
+    } else {
+        int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
+        if (elem_bytes == 4)
+            hipLaunchKernelGGL((select_elems_kernel<uint32_t, false>), dim3(grid), dim3(256), 0, stream,
+                               (const uint32_t*)input, index, (uint32_t*)out, B, N, K, E);
+        else
+            hipLaunchKernelGGL((select_elems_kernel<uint16_t, false>), dim3(grid), dim3(256), 0, stream,
+                               (const uint16_t*)input, index, (uint16_t*)out, B, N, K, E);
+    }
+    return gnnops_check_launch("index_select");
+}
+
+extern "C" int gnnops_index_select_planned(const void* input, const int32_t* rowptr, const int32_t* perm, void* out,
+                                           int64_t B, int64_t N, int64_t K, int64_t E, int elem_bytes,
+                                           gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "index_select_planned: negative size");
+    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "index_select_planned: elem_bytes %d",
+                   elem_bytes);
+    if (B * E * K == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(input && rowptr && perm && out, GNNOPS_EINVAL, "index_select_planned: null pointer");
+    const int64_t rowbytes = K * elem_bytes;
+    GNNOPS_REQUIRE(rowbytes % 16 == 0 && (uintptr_t)input % 16 == 0 && (uintptr_t)out % 16 == 0, GNNOPS_EUNSUPPORTED,
+                   "index_select_planned: rows must be 16-byte multiples and 16-byte aligned");
+    RowGeom g = row_geom(rowbytes / 16);
+    const int64_t items = B * g.chunks * N;
+    int grid = gnnops_grid_cap(gnnops_cdiv(items, 256 >> g.gshift), 256 * 32);
+    hipLaunchKernelGGL(select_rows_push_kernel, dim3(grid), dim3(256), 0, stream, (const char*)input, rowptr, perm,
+                       (char*)out, B, N, E, rowbytes, g.gshift, g.chunks);
+    return gnnops_check_launch("index_select_planned");
+}
+
+extern "C" int gnnops_gather(const void* input, const int64_t* index, void* out, int64_t B, int64_t N, int64_t K,
+                             int64_t E, int elem_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "gather: negative size");
+    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "gather: elem_bytes %d", elem_bytes);
+    if (B * E * K == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(input && index && out, GNNOPS_EINVAL, "gather: null pointer");
+    int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((select_elems_kernel<uint32_t, true>), dim3(grid), dim3(256), 0, stream,
+                           (const uint32_t*)input, index, (uint32_t*)out, B, N, K, E);
+    else
+        hipLaunchKernelGGL((select_elems_kernel<uint16_t, true>), dim3(grid), dim3(256), 0, stream,
+                           (const uint16_t*)input, index, (uint16_t*)out, B, N, K, E);
+    return gnnops_check_launch("gather");
+}
+
+extern "C" size_t gnnops_fused_select_sum_workspace_bytes(void) { return (size_t)FUSED_BLOCKS * sizeof(float); }
+
+extern "C" int gnnops_fused_index_select_sum(const void* input, const int64_t* index, float* d_sum_f32, int64_t B,
+                                             int64_t N, int64_t K, int64_t E, int dtype, void* workspace,
+                                             size_t workspace_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "fused_index_select_sum: negative size");
+    GNNOPS_REQUIRE(d_sum_f32 != nullptr, GNNOPS_EINVAL, "fused_index_select_sum: null output");
+    if (B * E * K == 0) {
+        if (hipMemsetAsync(d_sum_f32, 0, sizeof(float), stream) != hipSuccess)
+            return gnnops_check_launch("fused_index_select_sum memset");
+        return GNNOPS_OK;
+    }
+    GNNOPS_REQUIRE(input && index, GNNOPS_EINVAL, "fused_index_select_sum: null pointer");
+    GNNOPS_REQUIRE(workspace && workspace_bytes >= gnnops_fused_select_sum_workspace_bytes(), GNNOPS_EWORKSPACE,
+                   "fused_index_select_sum: workspace too small");
+    float* partial = (float*)workspace;
+    switch (dtype) {
+        case GNNOPS_F32: return launch_select_sum<float>(input, index, d_sum_f32, B, N, K, E, partial, stream);
+        case GNNOPS_F16: return launch_select_sum<__half>(input, index, d_sum_f32, B, N, K, E, partial, stream);
+        case GNNOPS_BF16: return launch_select_sum<__hip_bfloat16>(input, index, d_sum_f32, B, N, K, E, partial, stream);
+    }
+    gnnops_set_error("fused_index_select_sum: unknown dtype %d", dtype);
+    return GNNOPS_EINVAL;
+}

@@ -1,0 +1,171 @@
+// plan.hip — inverted index ("plan") of a destination index, built by a stable LSD radix sort.
+//
+// Replaces the implicit "who writes row n" structure behind torch_scatter.scatter_* /
+// Tensor.index_add_ (reference call sites: op_bm_scripts/benchmark_scatter_add.py:15-19,
+// benchmark_native_index_add_.py:13-16). The reference reaches those through atomics
+// (ops_to_kernels.md:5,7); on MI355X float atomics are capped at ~1.3 TB/s of added bytes
+// (MI355X_MICROARCH.md "Global float atomics"), so we sort once and reduce per destination.
+//
+// Sort engine: 8-bit digits, 8192-key tiles, three launches per pass:
+//   radix_hist    per-tile digit counts                  (reads keys)
+//   radix_scan    per-digit exclusive scan over tiles    (256 blocks)
+//   radix_scatter stable in-tile ranking by wave ballots, reorder through LDS, coalesced run writes
+// The same engine sorts fp32 keys for torch.sort (sort.hip) and 64-bit COO keys for coalesce.
+#include "common.h"
+#include "sort_engine.h"
+
+namespace {
+
+__global__ void index_max_kernel(const int64_t* __restrict__ index, int64_t E, int64_t* d_max) {
+    int64_t m = INT64_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t v = index[i];
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int64_t t = __shfl_xor(m, o);
+        m = t > m ? t : m;
+    }
+    if (lane_id() == 0 && m != INT64_MIN) atomicMax((long long*)d_max, (long long)m);
+}
+
+// rowptr[n] = first sorted position whose key is >= n. One thread per boundary i in [0, E].
+// Long runs of empty destinations (gap > GAP_INLINE) are queued and filled by fill_gaps_kernel so
+// that a skewed index (all edges on one node) does not serialise on one lane.
+constexpr int GAP_INLINE = 32;
+
+__global__ void rowptr_kernel(const uint32_t* __restrict__ sorted_keys, int64_t E, int64_t N,
+                              int32_t* __restrict__ rowptr, int32_t* __restrict__ gap_list,
+                              unsigned int* __restrict__ gap_count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= E; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t prev = (i == 0) ? -1 : (int64_t)sorted_keys[i - 1];
+        int64_t cur = (i == E) ? N : (int64_t)sorted_keys[i];
+        if (cur > N) cur = N;  // out-of-range keys cannot push writes past rowptr[N]
+        int64_t gap = cur - prev;
+        if (gap <= 0) continue;
+        if (gap <= GAP_INLINE) {
+            for (int64_t n = prev + 1; n <= cur; ++n) rowptr[n] = (int32_t)i;
+        } else {
+            unsigned int slot = atomicAdd(gap_count, 1u);
+            gap_list[3 * (int64_t)slot + 0] = (int32_t)(prev + 1);
+            gap_list[3 * (int64_t)slot + 1] = (int32_t)cur;
+            gap_list[3 * (int64_t)slot + 2] = (int32_t)i;
+        }
+    }
+}
+
+__global__ void fill_gaps_kernel(int32_t* __restrict__ rowptr, const int32_t* __restrict__ gap_list,
+                                 const unsigned int* __restrict__ gap_count) {
+    unsigned int cnt = *gap_count;
+    for (unsigned int g = blockIdx.x; g < cnt; g += gridDim.x) {
+        int64_t lo = gap_list[3 * (int64_t)g + 0], hi = gap_list[3 * (int64_t)g + 1];
+        int32_t v = gap_list[3 * (int64_t)g + 2];
+        for (int64_t n = lo + threadIdx.x; n <= hi; n += blockDim.x) rowptr[n] = v;
+    }
+}
+
+__global__ void iota_kernel(int32_t* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = (int32_t)i;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int key_bits_for(int64_t N) {
+    int bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < N) ++bits;
+    return bits;
+}
+
+}  // namespace
+
+extern "C" int gnnops_index_max(const int64_t* index, int64_t E, int64_t* d_max, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(d_max != nullptr, GNNOPS_EINVAL, "index_max: d_max is null");
+    GNNOPS_REQUIRE(E >= 0 && (E == 0 || index != nullptr), GNNOPS_EINVAL, "index_max: bad index/E");
+    const int64_t init = -1;
+    // d_max = -1, then atomicMax over the data (stream-ordered, no sync)
+    if (hipMemsetAsync(d_max, 0xff, sizeof(int64_t), stream) != hipSuccess)
+        return gnnops_check_launch("index_max memset");
+    (void)init;
+    if (E > 0) {
+        int grid = gnnops_grid_cap(gnnops_cdiv(E, 256 * 8));
+        hipLaunchKernelGGL(index_max_kernel, dim3(grid), dim3(256), 0, stream, index, E, d_max);
+    }
+    return gnnops_check_launch("index_max");
+}
+
+// Workspace layout (all 256-B aligned):
+//   keys_a[E] u32 | keys_b[E] u32 | vals_x[E] u32 | tile_hist[256*tiles] u32 | digit_total[256] u32 |
+//   gap_count u32 | gap_list[3*(N/32+2)] i32
+extern "C" size_t gnnops_plan_workspace_bytes(int64_t E, int64_t N) {
+    if (E < 0 || N < 0) return 0;
+    size_t tiles = (size_t)gnnops_cdiv(E > 0 ? E : 1, sortengine::TILE);
+    size_t b = 0;
+    b += 3 * align_up((size_t)E * 4, 256);
+    b += align_up(256 * tiles * 4, 256);
+    b += 256 * 4;
+    b += 256;
+    b += align_up(3 * ((size_t)N / GAP_INLINE + 2) * 4, 256);
+    return b;
+}
+
+extern "C" int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm,
+                                 void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(E >= 0 && N >= 0, GNNOPS_EINVAL, "plan_build: negative size");
+    GNNOPS_REQUIRE(E < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED,
+                   "plan_build: E and N must be < 2^31 (got E=%lld N=%lld)", (long long)E, (long long)N);
+    GNNOPS_REQUIRE(rowptr != nullptr, GNNOPS_EINVAL, "plan_build: rowptr is null");
+    if (E == 0) {
+        if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 4, stream) != hipSuccess)
+            return gnnops_check_launch("plan_build memset");
+        return GNNOPS_OK;
+    }
+    GNNOPS_REQUIRE(index != nullptr && perm != nullptr, GNNOPS_EINVAL, "plan_build: null pointer");
+    GNNOPS_REQUIRE(N > 0, GNNOPS_EINVAL, "plan_build: E > 0 needs N > 0");
+    GNNOPS_REQUIRE(workspace_bytes >= gnnops_plan_workspace_bytes(E, N) && workspace != nullptr,
+                   GNNOPS_EWORKSPACE, "plan_build: workspace %zu < %zu", workspace_bytes,
+                   gnnops_plan_workspace_bytes(E, N));
+
+    const size_t tiles = (size_t)gnnops_cdiv(E, sortengine::TILE);
+    char* w = (char*)workspace;
+    uint32_t* keys_a = (uint32_t*)w; w += align_up((size_t)E * 4, 256);
+    uint32_t* keys_b = (uint32_t*)w; w += align_up((size_t)E * 4, 256);
+    uint32_t* vals_x = (uint32_t*)w; w += align_up((size_t)E * 4, 256);
+    uint32_t* tile_hist = (uint32_t*)w; w += align_up(256 * tiles * 4, 256);
+    uint32_t* digit_total = (uint32_t*)w; w += 256 * 4;
+    unsigned int* gap_count = (unsigned int*)w; w += 256;
+    int32_t* gap_list = (int32_t*)w;
+
+    const int bits = key_bits_for(N);
+    const int passes = (bits + 7) / 8;
+
+    // Ping-pong so that the last pass lands in (keys_?, perm).
+    uint32_t* vals_y = (uint32_t*)perm;
+    const uint32_t* kin = nullptr;
+    const uint32_t* vin = nullptr;
+    uint32_t* sorted_keys = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_y = ((passes - 1 - p) % 2) == 0;  // last pass writes perm
+        uint32_t* kout = (p % 2 == 0) ? keys_a : keys_b;
+        uint32_t* vout = to_y ? vals_y : vals_x;
+        int rc;
+        if (p == 0)
+            rc = sortengine::pass_first_i64(index, kout, vout, E, 0, tile_hist, digit_total, (int)tiles, stream);
+        else
+            rc = sortengine::pass_u32(kin, vin, kout, vout, E, 8 * p, tile_hist, digit_total, (int)tiles, stream);
+        if (rc != GNNOPS_OK) return rc;
+        kin = kout; vin = vout; sorted_keys = kout;
+    }
+
+    if (hipMemsetAsync(gap_count, 0, sizeof(unsigned int), stream) != hipSuccess)
+        return gnnops_check_launch("plan_build memset gap_count");
+    {
+        int grid = gnnops_grid_cap(gnnops_cdiv(E + 1, 256));
+        hipLaunchKernelGGL(rowptr_kernel, dim3(grid), dim3(256), 0, stream, sorted_keys, E, N, rowptr, gap_list, gap_count);
+        hipLaunchKernelGGL(fill_gaps_kernel, dim3(512), dim3(256), 0, stream, rowptr, gap_list, gap_count);
+    }
+    return gnnops_check_launch("plan_build");
+}

@@ -1,0 +1,248 @@
+// scatter_elem.hip — element-wise scatter for a full-shape index (layout F): the literal shapes the
+// reference scripts time — torch_scatter.scatter_*(src, idx, dim) with idx.shape == src.shape
+// (op_bm_scripts/benchmark_scatter_add.py:67,78-84), `zeros_like(src).scatter_add_(dim, idx, src)`
+// (benchmark_scatter_add.py:22-25) and `scatter_(-1, idx, src, reduce="multiply")`
+// (benchmark_scatter_multiply.py:42-45).
+//
+// Every element has its own destination, so there is no row structure to sort on; this is the atomic
+// path. fp32 adds are single `global_atomic_add_f32` instructions; 16-bit sums/products accumulate in
+// an fp32 scratch and are rounded once; min/max (and products) use a CAS loop on the 32-bit word. The arg pass
+// picks the smallest position among ties (atomicMin on int64), which is what a sequential CPU loop gives.
+#include "common.h"
+
+namespace {
+
+__device__ inline void decode(int64_t o, int64_t E, int64_t K, int64_t& b, int64_t& e, int64_t& k) {
+    k = o % K;
+    const int64_t be = o / K;
+    e = be % E;
+    b = be / E;
+}
+
+#define GRID_STRIDE(o, total) \
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < (total); o += (int64_t)gridDim.x * blockDim.x)
+
+template <typename T>
+__global__ void fill_kernel(T* p, int64_t n, float v) {
+    GRID_STRIDE(i, n) Elem<T>::store(p + i, v);
+}
+__global__ void fill_i64_kernel(int64_t* p, int64_t n, int64_t v) { GRID_STRIDE(i, n) p[i] = v; }
+
+// ---- sum ----
+template <typename T>
+__global__ void scatter_add_f32acc_kernel(const T* __restrict__ src, const int64_t* __restrict__ index,
+                                          float* __restrict__ acc, int64_t B, int64_t E, int64_t K, int64_t N) {
+    GRID_STRIDE(o, B * E * K) {
+        int64_t b, e, k;
+        decode(o, E, K, b, e, k);
+        atomicAdd(acc + (b * N + index[o]) * K + k, Elem<T>::load(src + o));
+    }
+}
+__global__ void count_kernel(const int64_t* __restrict__ index, float* __restrict__ cnt, int64_t B, int64_t E,
+                             int64_t K, int64_t N) {
+    GRID_STRIDE(o, B * E * K) {
+        int64_t b, e, k;
+        decode(o, E, K, b, e, k);
+        atomicAdd(cnt + (b * N + index[o]) * K + k, 1.0f);
+    }
+}
+// out = round(acc [/ max(cnt,1)])
+template <typename T>
+__global__ void finish_kernel(T* __restrict__ out, const float* __restrict__ acc, const float* __restrict__ cnt,
+                              int64_t n) {
+    GRID_STRIDE(i, n) {
+        float v = acc[i];
+        if (cnt) {
+            const float c = cnt[i];
+            v = v / (c < 1.f ? 1.f : c);
+        }
+        Elem<T>::store(out + i, v);
+    }
+}
+template <typename T>
+__global__ void widen_kernel(const T* __restrict__ in, float* __restrict__ acc, int64_t n) {
+    GRID_STRIDE(i, n) acc[i] = Elem<T>::load(in + i);
+}
+
+// ---- CAS-based update of one element (fp32 word or a 16-bit half of a word) ----
+template <typename T, typename F>
+__device__ inline void atomic_update(T* addr, float v, F f) {
+    if constexpr (sizeof(T) == 4) {
+        unsigned int* w = reinterpret_cast<unsigned int*>(addr);
+        unsigned int old = *w;
+        while (true) {
+            const float cur = __uint_as_float(old);
+            const float nv = f(cur, v);
+            if (__float_as_uint(nv) == old) break;
+            const unsigned int got = atomicCAS(w, old, __float_as_uint(nv));
+            if (got == old) break;
+            old = got;
+        }
+    } else {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(addr);
+        unsigned int* w = reinterpret_cast<unsigned int*>(a & ~(uintptr_t)3);
+        const int sh = (a & 2) ? 16 : 0;
+        unsigned int old = *w;
+        while (true) {
+            unsigned short bits = (unsigned short)(old >> sh);
+            T curT = *reinterpret_cast<T*>(&bits);
+            const float nv = f(Elem<T>::load(&curT), v);
+            T nT;
+            Elem<T>::store(&nT, nv);
+            const unsigned short nbits = *reinterpret_cast<unsigned short*>(&nT);
+            if (nbits == bits) break;
+            const unsigned int neww = (old & ~(0xffffu << sh)) | ((unsigned int)nbits << sh);
+            const unsigned int got = atomicCAS(w, old, neww);
+            if (got == old) break;
+            old = got;
+        }
+    }
+}
+
+template <typename T, int R>
+__global__ void scatter_cas_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, T* __restrict__ out,
+                                   int64_t B, int64_t E, int64_t K, int64_t N) {
+    GRID_STRIDE(o, B * E * K) {
+        int64_t b, e, k;
+        decode(o, E, K, b, e, k);
+        T* dst = out + (b * N + index[o]) * K + k;
+        const float v = Elem<T>::load(src + o);
+        if constexpr (R == GNNOPS_MIN) {
+            atomic_update(dst, v, [](float a, float x) { return x < a ? x : a; });
+        } else {
+            atomic_update(dst, v, [](float a, float x) { return x > a ? x : a; });
+        }
+    }
+}
+
+template <typename T>
+__global__ void scatter_mul_f32acc_kernel(const T* __restrict__ src, const int64_t* __restrict__ index,
+                                          float* __restrict__ acc, int64_t B, int64_t E, int64_t K, int64_t N) {
+    GRID_STRIDE(o, B * E * K) {
+        int64_t b, e, k;
+        decode(o, E, K, b, e, k);
+        atomic_update(acc + (b * N + index[o]) * K + k, Elem<T>::load(src + o), [](float a, float x) { return a * x; });
+    }
+}
+
+// arg pass: smallest e whose value equals the reduced value.
+template <typename T>
+__global__ void scatter_arg_kernel(const T* __restrict__ src, const int64_t* __restrict__ index,
+                                   const T* __restrict__ out, int64_t* __restrict__ arg_out, int64_t B, int64_t E,
+                                   int64_t K, int64_t N) {
+    GRID_STRIDE(o, B * E * K) {
+        int64_t b, e, k;
+        decode(o, E, K, b, e, k);
+        const int64_t d = (b * N + index[o]) * K + k;
+        if (Elem<T>::load(src + o) == Elem<T>::load(out + d))
+            atomicMin(reinterpret_cast<unsigned long long*>(arg_out + d), (unsigned long long)e);
+    }
+}
+// torch_scatter: groups nothing reached (arg == E) become 0.
+template <typename T>
+__global__ void zero_empty_kernel(T* __restrict__ out, const int64_t* __restrict__ arg_out, int64_t n, int64_t E) {
+    GRID_STRIDE(i, n) if (arg_out[i] == E) Elem<T>::store(out + i, 0.f);
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int grid_for(int64_t n) { return gnnops_grid_cap(gnnops_cdiv(n, 256), 256 * 16); }
+
+template <typename T>
+int run(const void* src_, const int64_t* index, void* out_, int64_t* arg_out, int64_t B, int64_t E, int64_t K,
+        int64_t N, int reduce, int init_from_out, void* workspace, hipStream_t stream) {
+    const T* src = (const T*)src_;
+    T* out = (T*)out_;
+    const int64_t nout = B * N * K, nsrc = B * E * K;
+    const int gs = grid_for(nsrc), go = grid_for(nout);
+    constexpr bool IS_F32 = sizeof(T) == 4;
+    char* w = (char*)workspace;
+
+    if (reduce == GNNOPS_SUM || reduce == GNNOPS_MEAN || reduce == GNNOPS_MUL) {
+        // fp32 accumulator: `out` itself for fp32, a scratch for 16-bit types (rounded once at the end)
+        float* acc;
+        if (IS_F32) {
+            acc = (float*)out;
+        } else {
+            acc = (float*)w;
+            w += align_up((size_t)nout * 4, 256);
+        }
+        if (init_from_out) {
+            if (!IS_F32) hipLaunchKernelGGL((widen_kernel<T>), dim3(go), dim3(256), 0, stream, out, acc, nout);
+        } else {
+            hipLaunchKernelGGL((fill_kernel<float>), dim3(go), dim3(256), 0, stream, acc, nout,
+                               reduce == GNNOPS_MUL ? 1.f : 0.f);
+        }
+        float* cnt = nullptr;
+        if (reduce == GNNOPS_MEAN) {
+            cnt = (float*)w;
+            hipLaunchKernelGGL((fill_kernel<float>), dim3(go), dim3(256), 0, stream, cnt, nout, 0.f);
+            if (nsrc > 0) hipLaunchKernelGGL(count_kernel, dim3(gs), dim3(256), 0, stream, index, cnt, B, E, K, N);
+        }
+        if (nsrc > 0) {
+            if (reduce == GNNOPS_MUL)
+                hipLaunchKernelGGL((scatter_mul_f32acc_kernel<T>), dim3(gs), dim3(256), 0, stream, src, index, acc, B, E, K, N);
+            else
+                hipLaunchKernelGGL((scatter_add_f32acc_kernel<T>), dim3(gs), dim3(256), 0, stream, src, index, acc, B, E, K, N);
+        }
+        if (!IS_F32 || cnt)
+            hipLaunchKernelGGL((finish_kernel<T>), dim3(go), dim3(256), 0, stream, out, acc, cnt, nout);
+        return gnnops_check_launch("scatter_elementwise sum/mean/mul");
+    }
+
+    // min / max: exact on the stored type, CAS on the containing word
+    if (!init_from_out) {
+        const float ident = reduce == GNNOPS_MIN ? __builtin_huge_valf() : -__builtin_huge_valf();
+        hipLaunchKernelGGL((fill_kernel<T>), dim3(go), dim3(256), 0, stream, out, nout, ident);
+    }
+    if (nsrc > 0) {
+        if (reduce == GNNOPS_MIN)
+            hipLaunchKernelGGL((scatter_cas_kernel<T, GNNOPS_MIN>), dim3(gs), dim3(256), 0, stream, src, index, out, B, E, K, N);
+        else
+            hipLaunchKernelGGL((scatter_cas_kernel<T, GNNOPS_MAX>), dim3(gs), dim3(256), 0, stream, src, index, out, B, E, K, N);
+    }
+    if (arg_out) {
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(go), dim3(256), 0, stream, arg_out, nout, E);
+        if (nsrc > 0)
+            hipLaunchKernelGGL((scatter_arg_kernel<T>), dim3(gs), dim3(256), 0, stream, src, index, out, arg_out, B, E, K, N);
+        if (!init_from_out)
+            hipLaunchKernelGGL((zero_empty_kernel<T>), dim3(go), dim3(256), 0, stream, out, arg_out, nout, E);
+    }
+    return gnnops_check_launch("scatter_elementwise min/max");
+}
+
+}  // namespace
+
+extern "C" size_t gnnops_scatter_elementwise_workspace_bytes(int64_t B, int64_t N, int64_t K, int dtype, int reduce) {
+    if (B < 0 || N < 0 || K < 0) return 0;
+    const size_t nout = (size_t)(B * N * K);
+    size_t b = 0;
+    if ((reduce == GNNOPS_SUM || reduce == GNNOPS_MEAN || reduce == GNNOPS_MUL) && dtype != GNNOPS_F32)
+        b += align_up(nout * 4, 256);
+    if (reduce == GNNOPS_MEAN) b += align_up(nout * 4, 256);
+    return b;
+}
+
+extern "C" int gnnops_scatter_elementwise(const void* src, const int64_t* index, void* out, int64_t* arg_out,
+                                          int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce,
+                                          int init_from_out, void* workspace, size_t workspace_bytes,
+                                          gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(B >= 0 && E >= 0 && K >= 0 && N >= 0, GNNOPS_EINVAL, "scatter_elementwise: negative size");
+    GNNOPS_REQUIRE(reduce >= GNNOPS_SUM && reduce <= GNNOPS_MUL, GNNOPS_EINVAL, "scatter_elementwise: reduce %d", reduce);
+    GNNOPS_REQUIRE(!(reduce == GNNOPS_MEAN && init_from_out), GNNOPS_EINVAL,
+                   "scatter_elementwise: mean cannot start from out");
+    GNNOPS_REQUIRE((reduce != GNNOPS_MIN && reduce != GNNOPS_MAX) || arg_out != nullptr || init_from_out,
+                   GNNOPS_EINVAL, "scatter_elementwise: min/max without out needs arg_out (empty groups -> 0)");
+    if (B * N * K == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(out && (B * E * K == 0 || (src && index)), GNNOPS_EINVAL, "scatter_elementwise: null pointer");
+    const size_t need = gnnops_scatter_elementwise_workspace_bytes(B, N, K, dtype, reduce);
+    GNNOPS_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), GNNOPS_EWORKSPACE,
+                   "scatter_elementwise: workspace %zu < %zu", workspace_bytes, need);
+    switch (dtype) {
+        case GNNOPS_F32: return run<float>(src, index, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
+        case GNNOPS_F16: return run<__half>(src, index, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
+        case GNNOPS_BF16: return run<__hip_bfloat16>(src, index, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
+    }
+    gnnops_set_error("scatter_elementwise: unknown dtype %d", dtype);
+    return GNNOPS_EINVAL;
+}

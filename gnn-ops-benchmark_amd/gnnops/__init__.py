@@ -1,0 +1,38 @@
+"""gnnops — MI355X (gfx950) kernels behind the gnn-ops-benchmark op API.
+
+``import gnnops`` exposes the reference's op signatures on ROCm device tensors (see ops.py).
+``gnnops.install()`` additionally routes the ATen ops the reference scripts call by name
+(torch.index_select, Tensor.index_add_, torch.gather, Tensor.scatter_add_) to these kernels, and the
+sibling packages ``torch_scatter`` / ``torch_sparse`` in this directory provide the import seam
+(``from torch_scatter import scatter_add``) — so an unchanged ``op_bm_scripts/benchmark_*.py`` runs on them.
+"""
+from ._lib import GnnopsError, LIB_PATH, load as load_library
+from .ops import (
+    Plan,
+    clear_plan_cache,
+    gather,
+    get_plan,
+    index_add,
+    index_add_,
+    index_max,
+    index_select,
+    index_select_sum,
+    scatter,
+    scatter_add,
+    scatter_add_,
+    scatter_max,
+    scatter_mean,
+    scatter_min,
+    scatter_mul,
+    scatter_reduce_mul_,
+    scatter_sum,
+    set_plan_cache,
+)
+from .aten import install, uninstall, installed
+
+__all__ = [
+    "GnnopsError", "LIB_PATH", "load_library", "Plan", "clear_plan_cache", "gather", "get_plan", "index_add",
+    "index_add_", "index_max", "index_select", "index_select_sum", "scatter", "scatter_add", "scatter_add_",
+    "scatter_max", "scatter_mean", "scatter_min", "scatter_mul", "scatter_reduce_mul_", "scatter_sum",
+    "set_plan_cache", "install", "uninstall", "installed",
+]

@@ -1,0 +1,65 @@
+"""ctypes binding of the C ABI in include/gnnops.h (csrc/libgnnops.so, built for gfx950).
+
+There is no CPU or eager fallback: if the HIP library is missing this module raises at import of the
+first op, and every op raises on non-GPU tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgnnops.so")
+
+F32, F16, BF16 = 0, 1, 2
+SUM, MEAN, MIN, MAX, MUL = 0, 1, 2, 3, 4
+REDUCE_CODE = {"sum": SUM, "add": SUM, "mean": MEAN, "min": MIN, "max": MAX, "mul": MUL}
+
+# name -> (restype, argtypes); must list every symbol include/gnnops.h declares (tests check this).
+_i64, _vp, _ci, _sz = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+SIGNATURES = {
+    "gnnops_version": (_ci, []),
+    "gnnops_last_error": (ctypes.c_char_p, []),
+    "gnnops_index_max": (_ci, [_vp, _i64, _vp, _vp]),
+    "gnnops_plan_workspace_bytes": (_sz, [_i64, _i64]),
+    "gnnops_plan_build": (_ci, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "gnnops_segment_reduce": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp]),
+    "gnnops_scatter_elementwise_workspace_bytes": (_sz, [_i64, _i64, _i64, _ci, _ci]),
+    "gnnops_scatter_elementwise": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
+    "gnnops_index_select": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
+    "gnnops_index_select_planned": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
+    "gnnops_gather": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
+    "gnnops_fused_select_sum_workspace_bytes": (_sz, []),
+    "gnnops_fused_index_select_sum": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class GnnopsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgnnops.so; raises ImportError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"gnnops: HIP library not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C {os.path.dirname(LIB_PATH)}`. There is no CPU fallback."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gnnops_last_error().decode("utf-8", "replace")
+        if rc == 4:
+            raise NotImplementedError(f"gnnops.{what}: {msg}")
+        raise GnnopsError(f"gnnops.{what} failed (code {rc}): {msg}")

@@ -1,0 +1,406 @@
+"""Tensor-level front end of the HIP kernels: the reference's op signatures, on ROCm device tensors.
+
+Each function mirrors one call the reference's ``op_*`` bodies make (file:line under the reference
+root) — same names, argument order and meaning, same error behaviour where it is observable:
+
+  scatter / scatter_add / scatter_mean / scatter_min / scatter_max / scatter_mul
+      ~ torch_scatter (op_bm_scripts/benchmark_scatter_add.py:18, benchmark_scatter_mean.py:17,
+        benchmark_scatter_min.py:17, benchmark_scatter_max.py:17)
+  index_select ~ torch.index_select (benchmark_native_index_select.py:14)
+  index_add_   ~ Tensor.index_add_  (benchmark_native_index_add_.py:15)
+  gather       ~ torch.gather       (benchmark_native_gather.py:16)
+  scatter_add_ / scatter_reduce_mul_ ~ native in-place forms (benchmark_scatter_add.py:24,
+        benchmark_scatter_multiply.py:44)
+  index_select_sum ~ torch.index_select(...).sum() (benchmark_fused_index_select_reduce.py:12-20)
+
+PyTorch is used for device memory and streams only. Nothing here computes on the CPU: a CPU tensor
+or a missing HIP library raises.
+"""
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import F32, F16, BF16, REDUCE_CODE, check
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "gnnops: expected a ROCm device tensor (device='cuda'); there is no CPU path in this library"
+            )
+
+
+def _dtype_code(t, what):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise NotImplementedError(f"gnnops.{what}: dtype {t.dtype} is not supported (float32/float16/bfloat16)")
+
+
+def _bek(shape, dim):
+    B = 1
+    for s in shape[:dim]:
+        B *= s
+    K = 1
+    for s in shape[dim + 1:]:
+        K *= s
+    return B, shape[dim], K
+
+
+def _norm_dim(dim, ndim, what):
+    if ndim == 0:
+        raise IndexError(f"{what}: 0-dim tensors are not supported")
+    if dim < -ndim or dim >= ndim:
+        raise IndexError(f"Dimension out of range (expected to be in range of [{-ndim}, {ndim - 1}], but got {dim})")
+    return dim % ndim
+
+
+def _check_index(index, what):
+    if index.dtype != torch.int64:
+        raise RuntimeError(f"{what}: expected index of dtype int64, got {index.dtype}")
+
+
+# --------------------------------------------------------------------------------------------------
+# Plan: the inverted index of a destination index (rowptr, perm), built on device by plan.hip
+# --------------------------------------------------------------------------------------------------
+class Plan:
+    """Stable inverted index of a 1-D int64 ``index`` with values in [0, N).
+
+    ``rowptr`` int32 [N+1], ``perm`` int32 [E]: positions e with index[e] == n are
+    perm[rowptr[n]:rowptr[n+1]], ascending. Reusable across every op that shares the index
+    (scatter_*, index_add_, index_select push form) — build it once per static edge_index.
+    """
+
+    __slots__ = ("rowptr", "perm", "E", "N", "__weakref__")
+
+    def __init__(self, index, N):
+        _require_gpu(index)
+        _check_index(index, "Plan")
+        if index.dim() != 1:
+            raise ValueError("Plan: index must be 1-D")
+        index = index.contiguous()
+        L = _lib.load()
+        self.E = index.numel()
+        self.N = int(N)
+        dev = index.device
+        self.rowptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
+        self.perm = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
+        ws_bytes = L.gnnops_plan_workspace_bytes(self.E, self.N)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.gnnops_plan_build(index.data_ptr(), self.E, self.N, self.rowptr.data_ptr(), self.perm.data_ptr(),
+                                     ws.data_ptr(), ws_bytes, _stream())
+        check(rc, "plan_build")
+        # ws is returned to the caching allocator here; stream-ordered reuse keeps that safe.
+
+
+_plan_cache = {}          # id(index tensor) -> (weakref, version, N, Plan)
+_plan_cache_enabled = True
+_PLAN_CACHE_MAX = 8
+
+
+def set_plan_cache(enabled):
+    """Enable/disable reuse of plans across calls that pass the same (unmodified) index tensor object."""
+    global _plan_cache_enabled
+    _plan_cache_enabled = bool(enabled)
+    if not enabled:
+        _plan_cache.clear()
+
+
+def clear_plan_cache():
+    _plan_cache.clear()
+
+
+def get_plan(index, N):
+    """Plan for ``index`` (cached per tensor object + version counter while the cache is enabled)."""
+    if isinstance(index, Plan):
+        if index.N != N:
+            raise ValueError(f"Plan was built for N={index.N}, op needs N={N}")
+        return index
+    if not _plan_cache_enabled:
+        return Plan(index, N)
+    key = id(index)
+    hit = _plan_cache.get(key)
+    if hit is not None:
+        ref, version, n, plan = hit
+        if ref() is index and version == index._version and n == N:
+            return plan
+    plan = Plan(index, N)
+    if len(_plan_cache) >= _PLAN_CACHE_MAX:
+        _plan_cache.pop(next(iter(_plan_cache)))
+
+    def _drop(_ref, key=key):
+        _plan_cache.pop(key, None)
+
+    _plan_cache[key] = (weakref.ref(index, _drop), index._version, N, plan)
+    return plan
+
+
+def index_max(index):
+    """int(index.max()) computed by our reduction kernel; -1 for an empty index. Synchronises (like the
+    reference's implicit ``index.max()`` in torch_scatter when dim_size is None)."""
+    _require_gpu(index)
+    _check_index(index, "index_max")
+    index = index.contiguous()
+    out = torch.empty(1, dtype=torch.int64, device=index.device)
+    with torch.cuda.device(index.device):
+        rc = _lib.load().gnnops_index_max(index.data_ptr(), index.numel(), out.data_ptr(), _stream())
+    check(rc, "index_max")
+    return int(out.item())
+
+
+# --------------------------------------------------------------------------------------------------
+# scatter family
+# --------------------------------------------------------------------------------------------------
+def _row_index_of(index, src, dim):
+    """Return a contiguous 1-D index if `index` is (a broadcast of) a row index along `dim`, else None."""
+    if index.dim() == 1 and index.numel() == src.size(dim):
+        return index.contiguous()
+    if index.dim() == src.dim() and index.shape == src.shape:
+        # index.view(-1,1).expand_as(src) and friends: stride 0 everywhere but `dim`
+        if all(index.stride(d) == 0 or index.size(d) == 1 for d in range(index.dim()) if d != dim):
+            sl = [0] * index.dim()
+            sl[dim] = slice(None)
+            return index[tuple(sl)].contiguous()
+    return None
+
+
+def _broadcast_index(index, src, dim):
+    """torch_scatter.utils.broadcast: lift a lower-rank index to src's shape."""
+    if index.dim() == 1 and src.dim() > 1:
+        shape = [1] * src.dim()
+        shape[dim] = -1
+        index = index.view(shape)
+    while index.dim() < src.dim():
+        index = index.unsqueeze(-1)
+    return index.expand(src.shape)
+
+
+def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
+    """torch_scatter.scatter(src, index, dim, out, dim_size, reduce). min/max return (out, arg_out)."""
+    if reduce not in REDUCE_CODE:
+        raise ValueError(f"scatter: unknown reduce {reduce!r}")
+    rcode = REDUCE_CODE[reduce]
+    is_plan = isinstance(index, Plan)
+    _require_gpu(src, out, None if is_plan else index)
+    dt = _dtype_code(src, "scatter")
+    dim = _norm_dim(dim, src.dim(), "scatter")
+    src = src.contiguous()
+    B, E, K = _bek(src.shape, dim)
+    L = _lib.load()
+
+    if is_plan:
+        row_index = index
+        if index.E != E:
+            raise ValueError(f"scatter: plan has {index.E} positions, src.size({dim}) is {E}")
+    else:
+        _check_index(index, "scatter")
+        row_index = _row_index_of(index, src, dim)
+
+    if out is not None:
+        if out.dtype != src.dtype or not out.is_contiguous():
+            raise RuntimeError("scatter: out must be contiguous and of src's dtype")
+        N = out.size(dim)
+        init = 1
+        if reduce == "mean":
+            raise NotImplementedError("scatter: reduce='mean' with out= is not supported")
+    else:
+        init = 0
+        if dim_size is not None:
+            N = int(dim_size)
+        elif is_plan:
+            N = index.N
+        else:
+            N = index_max(index if row_index is None else row_index) + 1 if index.numel() else 0
+        shape = list(src.shape)
+        shape[dim] = N
+        out = torch.empty(shape, dtype=src.dtype, device=src.device)
+    want_arg = rcode in (_lib.MIN, _lib.MAX)
+    arg = torch.empty(out.shape, dtype=torch.int64, device=src.device) if want_arg else None
+
+    with torch.cuda.device(src.device):
+        if row_index is not None:
+            plan = get_plan(row_index, N)
+            rc = L.gnnops_segment_reduce(src.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(), out.data_ptr(),
+                                         arg.data_ptr() if want_arg else None, B, E, K, N, dt, rcode, init, _stream())
+            check(rc, "segment_reduce")
+        else:
+            full = _broadcast_index(index, src, dim).contiguous()
+            ws_bytes = L.gnnops_scatter_elementwise_workspace_bytes(B, N, K, dt, rcode)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=src.device)
+            rc = L.gnnops_scatter_elementwise(src.data_ptr(), full.data_ptr(), out.data_ptr(),
+                                              arg.data_ptr() if want_arg else None, B, E, K, N, dt, rcode, init,
+                                              ws.data_ptr(), ws_bytes, _stream())
+            check(rc, "scatter_elementwise")
+    return (out, arg) if want_arg else out
+
+
+def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
+    return scatter(src, index, dim, out, dim_size, "sum")
+
+
+def scatter_add(src, index, dim=-1, out=None, dim_size=None):
+    return scatter(src, index, dim, out, dim_size, "sum")
+
+
+def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
+    return scatter(src, index, dim, out, dim_size, "mean")
+
+
+def scatter_mul(src, index, dim=-1, out=None, dim_size=None):
+    return scatter(src, index, dim, out, dim_size, "mul")
+
+
+def scatter_min(src, index, dim=-1, out=None, dim_size=None):
+    return scatter(src, index, dim, out, dim_size, "min")
+
+
+def scatter_max(src, index, dim=-1, out=None, dim_size=None):
+    return scatter(src, index, dim, out, dim_size, "max")
+
+
+def scatter_add_(self, dim, index, src):
+    """Tensor.scatter_add_(dim, index, src): in place, returns self."""
+    _inplace_scatter(self, dim, index, src, "sum", "scatter_add_")
+    return self
+
+
+def scatter_reduce_mul_(self, dim, index, src):
+    """Tensor.scatter_(dim, index, src, reduce='multiply'): in place, returns self."""
+    _inplace_scatter(self, dim, index, src, "mul", "scatter_")
+    return self
+
+
+def _inplace_scatter(self, dim, index, src, reduce, what):
+    _require_gpu(self, index, src)
+    _check_index(index, what)
+    if self.dtype != src.dtype:
+        raise RuntimeError(f"{what}: expected self and src to have the same dtype")
+    if not self.is_contiguous():
+        raise NotImplementedError(f"{what}: self must be contiguous")
+    dim = _norm_dim(dim, self.dim(), what)
+    if index.dim() != src.dim() or index.dim() != self.dim():
+        raise RuntimeError(f"{what}: index, src and self must have the same number of dimensions")
+    if index.shape != src.shape:
+        # ATen allows index smaller than src; take the matching corner of src
+        src = src[tuple(slice(0, s) for s in index.shape)]
+    for d in range(self.dim()):
+        if d != dim and index.size(d) != self.size(d):
+            raise NotImplementedError(f"{what}: index must span self outside dim {dim}")
+    scatter(src, index, dim, out=self, reduce=reduce)
+
+
+# --------------------------------------------------------------------------------------------------
+# gathers
+# --------------------------------------------------------------------------------------------------
+def _elem_bytes(t, what):
+    eb = t.element_size()
+    if eb not in (2, 4):
+        raise NotImplementedError(f"gnnops.{what}: element size {eb} is not supported (2- or 4-byte types)")
+    return eb
+
+
+def index_select(input, dim, index, plan=None):
+    """torch.index_select(input, dim, index). With ``plan`` (a Plan of index over input.size(dim)) the push
+    form is used: every input row is read once and stored to all rows that select it."""
+    _require_gpu(input, index)
+    _check_index(index, "index_select")
+    if index.dim() > 1:
+        raise IndexError("index_select(): Index is supposed to be a vector")
+    dim = _norm_dim(dim, input.dim(), "index_select")
+    eb = _elem_bytes(input, "index_select")
+    input = input.contiguous()
+    index = index.contiguous().view(-1)
+    B, N, K = _bek(input.shape, dim)
+    E = index.numel()
+    shape = list(input.shape)
+    shape[dim] = E
+    out = torch.empty(shape, dtype=input.dtype, device=input.device)
+    L = _lib.load()
+    with torch.cuda.device(input.device):
+        if plan is not None:
+            if plan.E != E or plan.N != N:
+                raise ValueError("index_select: plan does not match index / input.size(dim)")
+            rc = L.gnnops_index_select_planned(input.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(),
+                                               out.data_ptr(), B, N, K, E, eb, _stream())
+        else:
+            rc = L.gnnops_index_select(input.data_ptr(), index.data_ptr(), out.data_ptr(), B, N, K, E, eb, _stream())
+    check(rc, "index_select")
+    return out
+
+
+def gather(input, dim, index):
+    """torch.gather(input, dim, index) for index spanning input outside ``dim``."""
+    _require_gpu(input, index)
+    _check_index(index, "gather")
+    if index.dim() != input.dim():
+        raise RuntimeError("gather(): Index tensor must have the same number of dimensions as input tensor")
+    dim = _norm_dim(dim, input.dim(), "gather")
+    eb = _elem_bytes(input, "gather")
+    for d in range(input.dim()):
+        if d != dim and index.size(d) != input.size(d):
+            raise NotImplementedError("gnnops.gather: index must span input outside `dim`")
+    input = input.contiguous()
+    index = index.contiguous()
+    B, N, K = _bek(input.shape, dim)
+    E = index.size(dim)
+    out = torch.empty(index.shape, dtype=input.dtype, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = _lib.load().gnnops_gather(input.data_ptr(), index.data_ptr(), out.data_ptr(), B, N, K, E, eb, _stream())
+    check(rc, "gather")
+    return out
+
+
+def index_add_(self, dim, index, source, alpha=1):
+    """Tensor.index_add_(dim, index, source): self.select(dim, index[j]) += source.select(dim, j). Returns self."""
+    is_plan = isinstance(index, Plan)
+    _require_gpu(self, source, None if is_plan else index)
+    if alpha != 1:
+        raise NotImplementedError("gnnops.index_add_: alpha != 1 is not supported")
+    if self.dtype != source.dtype:
+        raise RuntimeError("index_add_(): self and source must have the same dtype")
+    if not self.is_contiguous():
+        raise NotImplementedError("gnnops.index_add_: self must be contiguous")
+    dim = _norm_dim(dim, self.dim(), "index_add_")
+    if not is_plan:
+        _check_index(index, "index_add_")
+        if index.dim() != 1:
+            raise IndexError("index_add_(): Index is supposed to be a vector")
+        if index.numel() != source.size(dim):
+            raise IndexError("index_add_(): Number of indices should be equal to source.size(dim)")
+    scatter(source, index, dim, out=self, reduce="sum")
+    return self
+
+
+def index_add(input, dim, index, source):
+    """torch.index_add (out of place): clone + index_add_ (benchmark_fused_index_add_reduce.py:13)."""
+    return index_add_(input.clone(), dim, index, source)
+
+
+def index_select_sum(input, dim, index):
+    """fp32 value of ``torch.index_select(input, dim, index).sum()`` without materialising the gather
+    (benchmark_fused_index_select_reduce.py:12-20). Returns a 0-dim float32 device tensor."""
+    _require_gpu(input, index)
+    _check_index(index, "index_select_sum")
+    dt = _dtype_code(input, "index_select_sum")
+    dim = _norm_dim(dim, input.dim(), "index_select_sum")
+    input = input.contiguous()
+    index = index.contiguous().view(-1)
+    B, N, K = _bek(input.shape, dim)
+    L = _lib.load()
+    out = torch.empty((), dtype=torch.float32, device=input.device)
+    ws_bytes = L.gnnops_fused_select_sum_workspace_bytes()
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = L.gnnops_fused_index_select_sum(input.data_ptr(), index.data_ptr(), out.data_ptr(), B, N, K,
+                                             index.numel(), dt, ws.data_ptr(), ws_bytes, _stream())
+    check(rc, "fused_index_select_sum")
+    return out

@@ -1,0 +1,148 @@
+/*
+ * gnnops.h — C ABI of the MI355X (gfx950) operator library behind the gnn-ops-benchmark op API.
+ *
+ * This is the drop-in boundary. The reference (ryienh/gnn-ops-benchmark) has no FFI of its own:
+ * its hot path is the body of each `op_*` function in op_bm_scripts/benchmark_*.py, which calls a
+ * third-party CUDA op (torch_scatter / torch_sparse / ATen). Each entry point below replaces ONE such
+ * call; the reference call site it stands behind is cited as (file:line under the reference root).
+ *
+ * Conventions
+ *   - Plain pointers and sizes only. Every pointer is a DEVICE pointer unless marked "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). All work is enqueued on it;
+ *     nothing here synchronises the device, allocates device memory or retains a pointer after return.
+ *   - Tensors are viewed around the reduced/indexed dimension as [B, E, K] (source side) and [B, N, K]
+ *     (destination side): B = product of sizes before `dim`, K = product of sizes after it.
+ *     A 2-D [E, D] tensor indexed along dim 0 is B=1, K=D; along dim 1 it is B=E', K=1.
+ *   - `index` is int64 as in the reference (benchmark_scatter_add.py:78-84). Layout R = one index per
+ *     position along E (1-D row index, broadcast over B and K). Layout F = index of the full [B,E,K]
+ *     shape (what the reference scripts build).
+ *   - dtype codes: GNNOPS_F32/F16/BF16. 16-bit types are accumulated in fp32 and rounded once.
+ *   - Return value: 0 on success, a GNNOPS_E* code otherwise; gnnops_last_error() gives the text
+ *     (thread-local). Functions never throw and never call exit().
+ */
+#ifndef GNNOPS_H
+#define GNNOPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNOPS_ABI_VERSION 1
+
+enum gnnops_status {
+    GNNOPS_OK = 0,
+    GNNOPS_EINVAL = 1,    /* bad argument (shape, dtype, alignment, null pointer) */
+    GNNOPS_EWORKSPACE = 2,/* workspace too small */
+    GNNOPS_ELAUNCH = 3,   /* hipGetLastError() after a launch */
+    GNNOPS_EUNSUPPORTED = 4
+};
+
+enum gnnops_dtype { GNNOPS_F32 = 0, GNNOPS_F16 = 1, GNNOPS_BF16 = 2 };
+
+/* torch_scatter reduce names: scatter_add/scatter_sum, scatter_mean, scatter_min, scatter_max, scatter_mul */
+enum gnnops_reduce { GNNOPS_SUM = 0, GNNOPS_MEAN = 1, GNNOPS_MIN = 2, GNNOPS_MAX = 3, GNNOPS_MUL = 4 };
+
+typedef void* gnnops_stream_t;
+
+int gnnops_version(void);
+const char* gnnops_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * dim_size discovery. torch_scatter computes `int(index.max()) + 1` when dim_size is None
+ * (behind benchmark_scatter_add.py:18, benchmark_scatter_min.py:17). Writes max(index) (or -1 when
+ * E == 0) to *d_max (device int64). The caller decides when to read it back.
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_index_max(const int64_t* index, int64_t E, int64_t* d_max, gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inverted index ("plan") of a destination index: a stable counting sort of index[0..E) by value.
+ *   rowptr[n] .. rowptr[n+1]  = range of `perm` holding the positions e with index[e] == n,
+ *   in ascending e (stable) — so a per-destination sequential reduction visits contributions in the
+ *   same order as a sequential CPU loop over e.
+ * rowptr: int32[N+1], perm: int32[E] (E < 2^31). index values must lie in [0, N).
+ * Shared by scatter_* / index_add_ (segment reduce), index_select (push form), spmm (COO->CSR),
+ * coalesce and sparse transpose.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnnops_plan_workspace_bytes(int64_t E, int64_t N);
+int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N,
+                      int32_t* rowptr, int32_t* perm,
+                      void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Segment reduce over a plan — the kernel behind, with layout R:
+ *   torch_scatter.scatter_add / scatter_mean / scatter_min / scatter_max / scatter_mul
+ *     (benchmark_scatter_add.py:15-19, benchmark_scatter_mean.py:15-18,
+ *      benchmark_scatter_min.py:15-18, benchmark_scatter_max.py:15-18), and
+ *   Tensor.index_add_ (benchmark_native_index_add_.py:13-16) when init_from_out != 0.
+ * src [B,E,K] -> out [B,N,K].  out[b,n,k] = reduce over e in segment n of src[b,e,k].
+ *   init_from_out == 0 : out is overwritten; empty segments give 0 (SUM/MEAN/MIN/MAX) or 1 (MUL).
+ *   init_from_out != 0 : the reduction starts from the current out[b,n,k] (index_add_, `out=` given);
+ *                        MIN/MAX keep out where no contribution beats it; MEAN is not allowed.
+ * arg_out (MIN/MAX only, may be NULL): int64 [B,N,K]; position e of the first extremal contribution,
+ *   E where the segment is empty (torch_scatter's convention).
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_segment_reduce(const void* src, const int32_t* rowptr, const int32_t* perm,
+                          void* out, int64_t* arg_out,
+                          int64_t B, int64_t E, int64_t K, int64_t N,
+                          int dtype, int reduce, int init_from_out, gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Element-wise scatter, layout F (index has the shape of src) — what the reference scripts build
+ * (benchmark_scatter_add.py:67,78-84; native form `zeros_like(src).scatter_add_(dim, idx, src)`
+ * benchmark_scatter_add.py:22-25; `scatter_(-1, idx, src, reduce="multiply")`
+ * benchmark_scatter_multiply.py:42-45).  out[b, index[b,e,k], k] (op)= src[b,e,k].
+ *   init_from_out == 0 : the call initialises out itself (0 / identity) and, for MIN/MAX, sets groups
+ *                        nothing reached to 0 (needs arg_out); MEAN divides by max(count, 1).
+ *   init_from_out != 0 : contributions are combined into the existing out (`out=` / in-place forms).
+ * SUM/MEAN on 16-bit types use an fp32 scratch of B*N*K floats in `workspace` (MEAN: one more for
+ * the counts). MIN/MAX: value pass, then an arg pass choosing the smallest e among ties.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnnops_scatter_elementwise_workspace_bytes(int64_t B, int64_t N, int64_t K, int dtype, int reduce);
+int gnnops_scatter_elementwise(const void* src, const int64_t* index, void* out, int64_t* arg_out,
+                               int64_t B, int64_t E, int64_t K, int64_t N,
+                               int dtype, int reduce, int init_from_out,
+                               void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torch.index_select (benchmark_native_index_select.py:12-15; also the first half of
+ * benchmark_fused_index_select_reduce.py:12-20).  input [B,N,K], index int64 [E] -> out [B,E,K],
+ * out[b,e,k] = input[b,index[e],k].  Bit-exact copy; `elem_bytes` in {2,4}.
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_index_select(const void* input, const int64_t* index, void* out,
+                        int64_t B, int64_t N, int64_t K, int64_t E,
+                        int elem_bytes, gnnops_stream_t stream);
+
+/* Push form of the same op over a plan of `index` (each input row is read once and stored to every
+ * output row that selects it). Same result, different HBM traffic; see DESIGN.md. */
+int gnnops_index_select_planned(const void* input, const int32_t* rowptr, const int32_t* perm, void* out,
+                                int64_t B, int64_t N, int64_t K, int64_t E,
+                                int elem_bytes, gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torch.gather (benchmark_native_gather.py:14-17). input [B,N,K], index int64 [B,E,K] ->
+ * out[b,e,k] = input[b, index[b,e,k], k]. Bit-exact copy.
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_gather(const void* input, const int64_t* index, void* out,
+                  int64_t B, int64_t N, int64_t K, int64_t E,
+                  int elem_bytes, gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused index_select + full sum (benchmark_fused_index_select_reduce.py:12-20):
+ *   *d_sum_f32 = sum_{b,e,k} input[b,index[e],k], accumulated in fp32 (the reference's fp16 result
+ *   overflows to inf at its own sizes; the fp32 accumulator is the comparable quantity).
+ * The [B,E,K] intermediate is never written. Deterministic: per-block partials are combined in a
+ * fixed order by a second launch. workspace: gnnops_fused_select_sum_workspace_bytes().
+ * ------------------------------------------------------------------------------------------- */
+size_t gnnops_fused_select_sum_workspace_bytes(void);
+int gnnops_fused_index_select_sum(const void* input, const int64_t* index, float* d_sum_f32,
+                                  int64_t B, int64_t N, int64_t K, int64_t E,
+                                  int dtype, void* workspace, size_t workspace_bytes,
+                                  gnnops_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNOPS_H */

@@ -1,0 +1,129 @@
+"""CPU suite, part 2: the C-ABI library loads without a GPU and exports every symbol include/gnnops.h
+declares; host-side logic (argument checks, shape decomposition, harness mirror) behaves like the
+reference's call sites expect. No compute calls here."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gnnops.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gnnops_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import gnnops
+    from gnnops import _lib
+
+    names = _declared_symbols()
+    assert len(names) >= 13
+    lib = gnnops.load_library()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gnnops.h but not exported by libgnnops.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in gnnops/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert lib.gnnops_version() == 1
+    assert lib.gnnops_last_error() is not None
+
+
+def test_workspace_queries_are_host_only():
+    import gnnops
+
+    lib = gnnops.load_library()
+    e, n = 50_000_000, 10_000_000
+    ws = lib.gnnops_plan_workspace_bytes(e, n)
+    assert 3 * 4 * e <= ws <= 3 * 4 * e + 16 * (1 << 20)
+    assert lib.gnnops_plan_workspace_bytes(0, 0) > 0
+    assert lib.gnnops_scatter_elementwise_workspace_bytes(1, 100, 8, 0, 0) == 0      # f32 sum: in place
+    assert lib.gnnops_scatter_elementwise_workspace_bytes(1, 100, 8, 1, 0) >= 3200   # f16 sum: fp32 scratch
+    assert lib.gnnops_scatter_elementwise_workspace_bytes(1, 100, 8, 1, 1) >= 6400   # f16 mean: + counts
+    assert lib.gnnops_fused_select_sum_workspace_bytes() > 0
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    """The product has no CPU path: CPU tensors raise instead of running an eager fallback."""
+    import gnnops
+    import torch_scatter
+
+    src = torch.rand(8, 4)
+    idx = torch.randint(0, 3, (8,))
+    for fn in (gnnops.scatter_add, torch_scatter.scatter_min, torch_scatter.scatter_mean):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            fn(src, idx, 0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gnnops.index_select(src, 0, idx)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gnnops.Plan(idx, 3)
+
+
+def test_shape_decomposition_and_index_layout_detection():
+    from gnnops import ops
+
+    assert ops._bek((6, 5, 4), 0) == (1, 6, 20)
+    assert ops._bek((6, 5, 4), 1) == (6, 5, 4)
+    assert ops._bek((6, 5, 4), 2) == (30, 4, 1)
+    src = torch.zeros(6, 5)
+    row = torch.arange(6)
+    assert ops._row_index_of(row, src, 0) is row
+    exp = row.view(-1, 1).expand(6, 5)
+    assert torch.equal(ops._row_index_of(exp, src, 0), row)
+    assert ops._row_index_of(torch.zeros(6, 5, dtype=torch.int64), src, 0) is None  # genuine full index
+    col = torch.arange(5)
+    assert torch.equal(ops._row_index_of(col.view(1, -1).expand(6, 5), src, 1), col)
+    assert ops._broadcast_index(row, src, 0).shape == src.shape
+    with pytest.raises(IndexError):
+        ops._norm_dim(2, 2, "x")
+    assert ops._norm_dim(-1, 2, "x") == 1
+
+
+def test_torch_scatter_shim_surface():
+    """Names and signatures the reference imports (benchmark_scatter_add.py:5-7 etc.)."""
+    import inspect
+
+    import torch_scatter
+
+    for name in ("scatter", "scatter_add", "scatter_sum", "scatter_mean", "scatter_min", "scatter_max", "scatter_mul"):
+        fn = getattr(torch_scatter, name)
+        params = list(inspect.signature(fn).parameters)
+        assert params[:5] == ["src", "index", "dim", "out", "dim_size"], (name, params)
+    assert inspect.signature(torch_scatter.scatter).parameters["dim"].default == -1
+    assert inspect.signature(torch_scatter.scatter).parameters["reduce"].default == "sum"
+
+
+def test_harness_mirror(tmp_path, capsys):
+    """util / DataWriter counterparts keep the reference's observable behaviour
+    (graph_benchmark/benchmark/util.py:11-61, DataWriter.py:5-36; expected strings from SURVEY.md §8c)."""
+    import pandas as pd
+
+    from graph_benchmark.benchmark import util
+    from graph_benchmark.benchmark.DataWriter import DataWriter
+
+    util.setup_seed(42)
+    a = torch.rand(3)
+    util.setup_seed(42)
+    assert torch.equal(a, torch.rand(3))
+    assert util.combine_vals(1.5, 0.25) == "1.5 (0.25)"
+    with pytest.raises(Exception, match="Benchmarking only supported for CUDA"):
+        if not torch.cuda.is_available():
+            util.setup_cuda()
+        else:
+            raise Exception("Benchmarking only supported for CUDA")
+    util.print_input_dims((3, 3))
+    util.print_sparsity_info(0.5, torch.tensor([0.0, 1.0]))
+    out = capsys.readouterr().out
+    assert "DEBUG: Current input has dims 2" in out and "Sparsity info: 0.5" in out
+    for name in ("setup_seed", "print_util_info", "get_reserved_in_mb", "combine_vals", "setup_cuda", "empty_cache",
+                 "print_sparsity_info", "print_bm_stats", "print_input_dims"):
+        assert callable(getattr(util, name))
+
+    dw = DataWriter("x", "p")
+    dw.add_entry(["1", "0", "True"], (3, 3), 0, 1.5)
+    dw.write_data(str(tmp_path))
+    df = pd.read_csv(tmp_path / "x.csv", index_col=0)
+    assert list(df.columns) == ["p", "Input size (>95% mem util)*", "Sparsity", "GPU clock time"]
+    assert df.iloc[0].tolist() == ["1;0;True", "(3, 3)", 0, 1.5]

@@ -1,0 +1,325 @@
+"""GPU suite: parity of the HIP path (called through the C ABI, csrc/libgnnops.so) against the oracle.
+
+Bars (SURVEY.md §8c / BASELINE.json north_star):
+  - index_select / gather / plan (rowptr, perm) / arg_out: bit-exact.
+  - layout R reductions (plan path): the kernel adds in the same sequential order as the oracle and
+    rounds 16-bit outputs once, so fp32, fp16 and bf16 results are required to be BIT-EXACT too.
+  - layout F sums/means/products use float atomics whose arrival order is not fixed:
+    fp32 |err| <= 1e-5 * sqrt(max_degree) * max|partial|, fp16 rtol 1e-3, bf16 rtol 8e-3 (the tolerances
+    SURVEY.md §8c states); F min/max and their arg are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TORCH_DT, assert_bits_equal, f32_of, from_np, load_golden, to_np
+
+pytestmark = pytest.mark.gpu
+
+REDUCES = ["sum", "mean", "mul", "min", "max"]
+RTOL = {"f32": 1e-5, "f16": 1e-3, "bf16": 8e-3}
+
+
+@pytest.fixture(scope="module")
+def gnnops():
+    import gnnops as g
+
+    g.load_library()
+    g.set_plan_cache(False)  # every call builds its plan: exercises plan_build everywhere
+    yield g
+    g.set_plan_cache(True)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+def _close(got, exp, dname, degree, what):
+    g32, e32 = f32_of(got, dname).astype(np.float64), f32_of(exp, dname).astype(np.float64)
+    tol = RTOL[dname] * max(1.0, np.sqrt(degree))
+    err = np.abs(g32 - e32)
+    bound = tol * np.maximum(np.abs(e32), 1.0)
+    assert (err <= bound).all(), f"{what}: max err {err.max()} (bound {bound[err.argmax()]})"
+
+
+# ------------------------------------------------------------------------------------------------
+# plan (stable inverted index)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("E,N,kind", [
+    (0, 5, "uniform"), (1, 1, "uniform"), (7, 3, "uniform"), (8192, 100, "uniform"), (8193, 257, "uniform"),
+    (100_000, 70_000, "uniform"), (300_000, 256, "uniform"), (200_000, 1 << 17, "uniform"),
+    (50_000, 1, "uniform"), (60_000, 1000, "allsame"), (40_000, 5_000_000, "uniform"), (123_457, 9, "sorted"),
+    (70_000, 20_000_000, "high"),
+])
+def test_plan_matches_oracle(gnnops, oracle, E, N, kind):
+    g = torch.Generator().manual_seed(42)
+    if kind == "allsame":
+        idx = torch.full((E,), N - 1, dtype=torch.int64)
+    elif kind == "high":  # exercises the 4th radix pass and long empty-destination runs
+        idx = torch.randint(N - 1000, N, (E,), generator=g)
+    else:
+        idx = torch.randint(0, N, (E,), generator=g)
+        if kind == "sorted":
+            idx = idx.sort().values
+    plan = gnnops.Plan(idx.cuda(), N)
+    rowptr, perm = oracle.plan(idx.numpy(), N)
+    assert_bits_equal(plan.rowptr.cpu().numpy(), rowptr, "rowptr")
+    assert_bits_equal(plan.perm.cpu().numpy()[:E], perm, "perm")
+
+
+def test_index_max(gnnops):
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 123456, (1_000_003,), generator=g)
+    assert gnnops.index_max(idx.cuda()) == int(idx.max())
+    assert gnnops.index_max(torch.empty(0, dtype=torch.int64, device="cuda")) == -1
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures (inputs and expected outputs committed under tests/golden)
+# ------------------------------------------------------------------------------------------------
+def test_scatter_golden(gnnops):
+    g = load_golden("scatter_golden.npz")
+    keys = sorted(k[:-4] for k in g.files if k.startswith("scatter_") and k.endswith("_src"))
+    for key in keys:
+        dname = key.rsplit("_", 1)[1]
+        layout = key.split("_")[-2]
+        dim = int(key.split("_d")[1][0])
+        src = from_np(g[key + "_src"], dname).cuda()
+        idx = torch.from_numpy(g[key + "_idx"]).cuda()
+        N = int(g[key + "_N"])
+        E = src.shape[dim]
+        for r in REDUCES:
+            res = gnnops.scatter(src, idx, dim, dim_size=N, reduce=r)
+            exp = g[f"{key}_{r}"]
+            if r in ("min", "max"):
+                out, arg = res
+                assert_bits_equal(arg.cpu().numpy(), g[f"{key}_arg{r}"], f"{key} arg{r}")
+                assert_bits_equal(to_np(out), exp, f"{key} {r}")
+            elif layout == "R":
+                assert_bits_equal(to_np(res), exp, f"{key} {r}")
+            else:
+                _close(to_np(res), exp, dname, E, f"{key} {r}")
+    out, arg = gnnops.scatter_min(torch.from_numpy(g["known_min_src"]).cuda(), torch.from_numpy(g["known_min_idx"]).cuda(), 1)
+    assert_bits_equal(out.cpu().numpy(), g["known_min_out"], "known min")
+    assert_bits_equal(arg.cpu().numpy(), g["known_min_arg"], "known arg")
+    res = gnnops.scatter_add(torch.from_numpy(g["allsame_src"]).cuda(), torch.from_numpy(g["allsame_idx"]).cuda(), 0)
+    assert_bits_equal(res.cpu().numpy(), g["allsame_sum"], "all-same (dim_size from index.max()+1)")
+    src = torch.from_numpy(g["ref223_src"]).cuda()
+    idx = torch.from_numpy(g["ref223_idx"].astype(np.int64)).cuda()
+    for dim in (0, 1):
+        res = gnnops.scatter_add(src, idx, dim=dim)
+        _close(to_np(res), g[f"ref223_d{dim}_sum"], "f16", 223, f"ref223 d{dim}")
+
+
+def test_native_golden(gnnops):
+    g = load_golden("native_golden.npz")
+    keys = sorted(k[:-3] for k in g.files if k.endswith("_in"))
+    for key in keys:
+        dname = key.rsplit("_", 1)[1]
+        dim = int(key.split("_d")[1][0])
+        inp = from_np(g[key + "_in"], dname).cuda()
+        idx = torch.from_numpy(g[key + "_idx"]).cuda()
+        assert_bits_equal(to_np(gnnops.index_select(inp, dim, idx)), g[key + "_index_select"], key + " index_select")
+        gidx = torch.from_numpy(g[key + "_gidx"]).cuda()
+        assert_bits_equal(to_np(gnnops.gather(inp, dim, gidx)), g[key + "_gather"], key + " gather")
+        source = from_np(g[key + "_source"], dname).cuda()
+        got = gnnops.index_add_(inp.clone(), dim, idx, source)
+        assert_bits_equal(to_np(got), g[key + "_index_add"], key + " index_add_")
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded inputs vs the oracle
+# ------------------------------------------------------------------------------------------------
+R_SHAPES = [
+    # (shape, dim, N)   row form: K*elem multiple of 16 B; element form otherwise
+    ((5000, 64), 0, 1000),      # BASELINE config 1 shape family (N=100k,E=500k,D=64) scaled
+    ((3000, 128), 0, 700),      # config 2 row length
+    ((2000, 256), 0, 300),      # config 3 row length
+    ((1500, 320), 0, 200),      # > 1 KiB rows: several column chunks
+    ((999, 12), 0, 50),         # 48-byte rows: 3 of 4 lanes active
+    ((777, 7), 0, 40),          # unaligned rows -> element kernel
+    ((64, 3000), 1, 500),       # dim 1: B=64, K=1 (reference index_add_/index_select dim 1 shape)
+    ((6, 400, 16), 1, 37),      # 3-D, middle dim
+    ((4096, 1), 0, 10),         # K = 1
+]
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,dim,N", R_SHAPES)
+def test_scatter_row_index_bit_exact(gnnops, oracle, shape, dim, N, dname):
+    g = torch.Generator().manual_seed(42)
+    src = (torch.rand(shape, generator=g) * 4 - 2).to(TORCH_DT[dname])
+    E = shape[dim]
+    idx = torch.randint(0, N, (E,), generator=g)
+    idx[idx == 1] = 0  # destination 1 stays empty
+    dsrc, didx = src.cuda(), idx.cuda()
+    for r in REDUCES:
+        res = gnnops.scatter(dsrc, didx, dim, dim_size=N, reduce=r)
+        exp = oracle.scatter(to_np(src), idx.numpy(), dim, dim_size=N, reduce=r, dtype=dname)
+        if r in ("min", "max"):
+            assert_bits_equal(res[1].cpu().numpy(), exp[1], f"arg{r}")
+            res, exp = res[0], exp[0]
+        assert_bits_equal(to_np(res), exp, f"{r} {shape} d{dim} {dname}")
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,dim,N", [((223, 223), 0, 111), ((223, 223), 1, 27), ((40, 50, 6), 1, 9), ((1000,), 0, 13)])
+def test_scatter_full_index(gnnops, oracle, shape, dim, N, dname):
+    g = torch.Generator().manual_seed(43)
+    src = (torch.rand(shape, generator=g) + 0.5).to(TORCH_DT[dname])  # positive, O(1): products stay finite
+    idx = torch.randint(0, N, shape, generator=g)
+    E = shape[dim]
+    for r in REDUCES:
+        res = gnnops.scatter(src.cuda(), idx.cuda(), dim, dim_size=N + 1, reduce=r)  # last destination empty
+        exp = oracle.scatter(to_np(src), idx.numpy(), dim, dim_size=N + 1, reduce=r, dtype=dname)
+        if r in ("min", "max"):
+            assert_bits_equal(res[1].cpu().numpy(), exp[1], f"arg{r}")
+            assert_bits_equal(to_np(res[0]), exp[0], r)
+        elif r == "mul":
+            g32, e32 = f32_of(to_np(res), dname).astype(np.float64), f32_of(exp, dname).astype(np.float64)
+            rel = np.abs(g32 - e32) / np.maximum(np.abs(e32), 1e-30)
+            assert rel.max() <= RTOL[dname] * E, f"mul rel err {rel.max()}"
+        else:
+            _close(to_np(res), exp, dname, E, f"{r} {shape} d{dim} {dname}")
+
+
+def test_scatter_out_and_inplace_forms(gnnops, oracle):
+    g = torch.Generator().manual_seed(7)
+    src = torch.rand(500, 32, generator=g)
+    idx = torch.randint(0, 60, (500,), generator=g)
+    base = torch.rand(60, 32, generator=g)
+    out = base.clone().cuda()
+    ret = gnnops.scatter_add(src.cuda(), idx.cuda(), 0, out=out)
+    assert ret.data_ptr() == out.data_ptr()
+    assert_bits_equal(out.cpu().numpy(), oracle.scatter(src.numpy(), idx.numpy(), 0, out=base.numpy()), "out=")
+    # expanded index (PyG idiom index.view(-1,1).expand_as(src)) takes the row path -> bit exact
+    res = gnnops.scatter_add(src.cuda(), idx.cuda().view(-1, 1).expand(500, 32), 0, dim_size=60)
+    assert_bits_equal(res.cpu().numpy(), oracle.scatter(src.numpy(), idx.numpy(), 0, dim_size=60), "expanded index")
+    # native in-place forms (benchmark_scatter_add.py:22-25, benchmark_scatter_multiply.py:42-45)
+    full = torch.randint(0, 500, (500, 32), generator=g)
+    temp = torch.zeros_like(src).cuda()
+    assert gnnops.scatter_add_(temp, 0, full.cuda(), src.cuda()) is temp
+    exp = oracle.scatter(src.numpy(), full.numpy(), 0, out=np.zeros((500, 32), np.float32))
+    _close(temp.cpu().numpy(), exp, "f32", 16, "scatter_add_")
+    temp = torch.zeros_like(src).cuda()
+    gnnops.scatter_reduce_mul_(temp, -1, torch.randint(0, 32, (500, 32), generator=g).cuda(), src.cuda())
+    assert torch.count_nonzero(temp).item() == 0  # the reference's op: 0 * x stays 0
+    # min with out=: keeps out where nothing beats it, no zero fill
+    mo = torch.full((60, 32), 0.25).cuda()
+    got, arg = gnnops.scatter_min(src.cuda(), idx.cuda(), 0, out=mo)
+    eo, ea = oracle.scatter(src.numpy(), idx.numpy(), 0, out=np.full((60, 32), 0.25, np.float32), reduce="min")
+    assert_bits_equal(got.cpu().numpy(), eo, "min out=")
+    assert_bits_equal(arg.cpu().numpy(), ea, "min out= arg")
+
+
+def test_plan_reuse_and_cache(gnnops, oracle):
+    g = torch.Generator().manual_seed(9)
+    src = torch.rand(20000, 64, generator=g)
+    idx = torch.randint(0, 3000, (20000,), generator=g)
+    didx = idx.cuda()
+    plan = gnnops.Plan(didx, 3000)
+    exp = oracle.scatter(src.numpy(), idx.numpy(), 0, dim_size=3000)
+    assert_bits_equal(gnnops.scatter_add(src.cuda(), plan, 0).cpu().numpy(), exp, "explicit plan")
+    gnnops.set_plan_cache(True)
+    try:
+        a = gnnops.get_plan(didx, 3000)
+        assert gnnops.get_plan(didx, 3000) is a
+        didx[0] = (didx[0] + 1) % 3000  # in-place edit bumps the version counter -> rebuild
+        b = gnnops.get_plan(didx, 3000)
+        assert b is not a
+        idx2 = didx.cpu()
+        assert_bits_equal(gnnops.scatter_add(src.cuda(), didx, 0, dim_size=3000).cpu().numpy(),
+                          oracle.scatter(src.numpy(), idx2.numpy(), 0, dim_size=3000), "after edit")
+    finally:
+        gnnops.set_plan_cache(False)
+    # push-form index_select over the same plan == pull form == oracle
+    table = torch.rand(3000, 64, generator=g)
+    idx3 = torch.randint(0, 3000, (20000,), generator=g)
+    p3 = gnnops.Plan(idx3.cuda(), 3000)
+    exp = oracle.index_select(table.numpy(), 0, idx3.numpy())
+    assert_bits_equal(gnnops.index_select(table.cuda(), 0, idx3.cuda()).cpu().numpy(), exp, "pull")
+    assert_bits_equal(gnnops.index_select(table.cuda(), 0, idx3.cuda(), plan=p3).cpu().numpy(), exp, "push")
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,dim", [((3000, 128), 0), ((2738, 2738), 0), ((500, 1000), 1), ((777, 7), 0),
+                                       ((5, 300, 24), 1), ((1500, 320), 0)])
+def test_index_select_and_gather_bit_exact(gnnops, oracle, shape, dim, dname):
+    g = torch.Generator().manual_seed(11)
+    inp = torch.rand(shape, generator=g).to(TORCH_DT[dname])
+    Nn = shape[dim]
+    for E in (Nn, max(1, Nn // 8)):  # reduce factors 1 and 8 (benchmark_native_index_select.py:62)
+        idx = torch.randint(0, Nn, (E,), generator=g)
+        got = gnnops.index_select(inp.cuda(), dim, idx.cuda())
+        assert_bits_equal(to_np(got), oracle.index_select(to_np(inp), dim, idx.numpy()), f"index_select E={E}")
+    if inp.numel() <= 2_000_000:
+        gidx = torch.randint(0, Nn, shape, generator=g)
+        got = gnnops.gather(inp.cuda(), dim, gidx.cuda())
+        assert_bits_equal(to_np(got), oracle.gather(to_np(inp), dim, gidx.numpy()), "gather")
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16"])
+def test_index_add_reference_shape(gnnops, oracle, dname):
+    """dim=1, index length = input.shape[1] (benchmark_native_index_add_.py:62,79-86)."""
+    g = torch.Generator().manual_seed(13)
+    L = 1581
+    inp = torch.rand(L, L, generator=g).to(TORCH_DT[dname])
+    source = torch.rand(L, L, generator=g).to(TORCH_DT[dname])
+    idx = torch.randint(0, L, (L,), generator=g)
+    got = gnnops.index_add_(inp.clone().cuda(), 1, idx.cuda(), source.cuda())
+    exp = oracle.index_add_(to_np(inp), 1, idx.numpy(), to_np(source), dtype=dname)
+    assert_bits_equal(to_np(got), exp, "index_add_ dim 1")
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
+def test_fused_index_select_sum(gnnops, oracle, dname):
+    g = torch.Generator().manual_seed(17)
+    inp = torch.rand(2738, 2738, generator=g).to(TORCH_DT[dname])
+    idx = torch.randint(0, 2738, (2738,), generator=g)
+    for dim in (0, 1):
+        got = gnnops.index_select_sum(inp.cuda(), dim, idx.cuda()).item()
+        exp = oracle.index_select_sum(to_np(inp), dim, idx.numpy(), dtype=dname)
+        assert abs(got - exp) <= 1e-5 * abs(exp), (got, exp)  # fp32 tree sum vs double
+    small = torch.rand(7, 5, generator=g).to(TORCH_DT[dname])
+    got = gnnops.index_select_sum(small.cuda(), 1, torch.tensor([4, 0, 0]).cuda()).item()
+    assert abs(got - oracle.index_select_sum(to_np(small), 1, np.array([4, 0, 0]), dtype=dname)) < 1e-5
+
+
+def test_aten_overrides_route_to_hip(gnnops, oracle):
+    """The ATen seam: unchanged script text (torch.index_select, Tensor.index_add_, ...) reaches our kernels."""
+    g = torch.Generator().manual_seed(19)
+    inp = torch.rand(300, 64, generator=g)
+    idx = torch.randint(0, 300, (450,), generator=g)
+    source = torch.rand(450, 64, generator=g)
+    gnnops.install()
+    try:
+        assert gnnops.installed()
+        sel = torch.index_select(inp.cuda(), 0, idx.cuda())
+        acc = inp.clone().cuda()
+        acc.index_add_(0, idx.cuda(), source.cuda())
+        gat = torch.gather(inp.cuda(), 0, idx[:300].view(-1, 1).expand(300, 64).contiguous().cuda())
+        tmp = torch.zeros(300, 64, device="cuda")
+        tmp.scatter_add_(0, idx.cuda().view(-1, 1).expand(450, 64), source.cuda())
+    finally:
+        gnnops.uninstall()
+    assert not gnnops.installed()
+    assert_bits_equal(sel.cpu().numpy(), oracle.index_select(inp.numpy(), 0, idx.numpy()), "aten index_select")
+    assert_bits_equal(acc.cpu().numpy(), oracle.index_add_(inp.numpy(), 0, idx.numpy(), source.numpy()), "aten index_add_")
+    assert_bits_equal(gat.cpu().numpy(), oracle.index_select(inp.numpy(), 0, idx[:300].numpy()), "aten gather")
+    assert_bits_equal(tmp.cpu().numpy(), oracle.scatter(source.numpy(), idx.numpy(), 0, dim_size=300), "aten scatter_add_")
+    # and the stock kernels are back afterwards
+    assert torch.equal(torch.index_select(inp.cuda(), 0, idx.cuda()).cpu(), sel.cpu())
+
+
+def test_config1_scatter_add(gnnops, oracle):
+    """BASELINE config 1 at full size: N=100k, E=500k, D=64 fp32 (the reference's CPU-runnable case)."""
+    g = torch.Generator().manual_seed(42)
+    N, E, D = 100_000, 500_000, 64
+    src = torch.rand(E, D, generator=g)
+    idx = torch.randint(0, N, (E,), generator=g)
+    got = gnnops.scatter_add(src.cuda(), idx.cuda(), dim=0)
+    exp = oracle.scatter(src.numpy(), idx.numpy(), 0)
+    assert_bits_equal(got.cpu().numpy(), exp, "config 1")
