@@ -232,9 +232,16 @@ def extra_ops(torch, gnnops, src, index, N, E, D):
     rec("index_add__warm", lambda: gnnops.index_add_(acc, 0, plan, src), "index_add_")
     del acc
     table = torch.rand(N, D, device=src.device)
-    rec("index_select_pull", lambda: gnnops.index_select(table, 0, index), "index_select")
-    rec("index_select_push_warm", lambda: gnnops.index_select(table, 0, index, plan=plan), "index_select")
-    rec("index_select_push_cold", lambda: gnnops.index_select(table, 0, index, plan=gnnops.Plan(index, N)), "index_select")
+    from gnnops import ops as _ops
+
+    rec("index_select_cold", lambda: gnnops.index_select(table, 0, index), "index_select")  # auto: plan + push
+    rec("index_select_warm", lambda: gnnops.index_select(table, 0, index, plan=plan), "index_select")
+    saved = _ops._PUSH_MIN_TABLE_BYTES
+    _ops._PUSH_MIN_TABLE_BYTES = 1 << 62  # force the pull form for comparison
+    try:
+        rec("index_select_pull", lambda: gnnops.index_select(table, 0, index), "index_select")
+    finally:
+        _ops._PUSH_MIN_TABLE_BYTES = saved
     return res
 
 

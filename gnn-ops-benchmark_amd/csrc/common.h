@@ -33,6 +33,28 @@ static inline int gnnops_grid_cap(int64_t want, int64_t cap = 256 * 16) {
 // ---- 16-byte vector type used for every wide global access ----
 struct __attribute__((aligned(16))) u32x4 { uint32_t x, y, z, w; };
 
+// ---- 16-byte global accesses, optionally nontemporal (streamed-once data) ----
+template <bool NT>
+__device__ inline u32x4 load16(const void* p) {
+    if constexpr (NT) {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+        u32x4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r;
+    } else {
+        return *reinterpret_cast<const u32x4*>(p);
+    }
+}
+template <bool NT>
+__device__ inline void store16(void* p, const u32x4& v) {
+    if constexpr (NT) {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        v4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
+    } else {
+        *reinterpret_cast<u32x4*>(p) = v;
+    }
+}
+
 // ---- element traits: fp32 compute for every storage type ----
 template <typename T> struct Elem;
 template <> struct Elem<float> {

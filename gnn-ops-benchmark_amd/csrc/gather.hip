@@ -11,7 +11,8 @@ namespace {
 constexpr int ROWS_IN_FLIGHT = 4;
 
 // Pull form. Row = rowbytes bytes (multiple of 16), G = 2^gshift lanes per row, chunks of G*16 bytes.
-// item = ((b*chunks + c) * E + e)
+// item = ((b*chunks + c) * E + e). RIF rows are in flight per lane group.
+template <bool NT_LD, bool NT_ST, int RIF>
 __global__ __launch_bounds__(256) void select_rows_kernel(const char* __restrict__ in, const int64_t* __restrict__ index,
                                                           char* __restrict__ out, int64_t B, int64_t N, int64_t E,
                                                           int64_t rowbytes, int gshift, int chunks) {
@@ -20,12 +21,14 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const char* __restrict
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
     const int gl = (int)(gtid & (G - 1));
     const int64_t items = B * (int64_t)chunks * E;
-    for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * ROWS_IN_FLIGHT) {
-        int64_t srcoff[ROWS_IN_FLIGHT], dstoff[ROWS_IN_FLIGHT];
+    for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * RIF) {
+        const char* sp[RIF];
+        char* dp[RIF];
 #pragma unroll
-        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+        for (int u = 0; u < RIF; ++u) {
             const int64_t item = item0 + (int64_t)u * ngroups;
-            srcoff[u] = -1;
+            sp[u] = nullptr;
+            dp[u] = nullptr;
             if (item < items) {
                 const int64_t e = item % E;
                 const int64_t bc = item / E;
@@ -34,23 +37,24 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const char* __restrict
                 const int64_t colb = ((int64_t)c * G + gl) * 16;
                 if (colb < rowbytes) {
                     const int64_t n = index[e];
-                    srcoff[u] = (b * N + n) * rowbytes + colb;
-                    dstoff[u] = (b * E + e) * rowbytes + colb;
+                    sp[u] = in + (b * N + n) * rowbytes + colb;
+                    dp[u] = out + (b * E + e) * rowbytes + colb;
                 }
             }
         }
-        u32x4 v[ROWS_IN_FLIGHT];
+        u32x4 v[RIF];
 #pragma unroll
-        for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
-            if (srcoff[u] >= 0) v[u] = *reinterpret_cast<const u32x4*>(in + srcoff[u]);
+        for (int u = 0; u < RIF; ++u)
+            if (sp[u]) v[u] = load16<NT_LD>(sp[u]);
 #pragma unroll
-        for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
-            if (srcoff[u] >= 0) *reinterpret_cast<u32x4*>(out + dstoff[u]) = v[u];
+        for (int u = 0; u < RIF; ++u)
+            if (sp[u]) store16<NT_ST>(dp[u], v[u]);
     }
 }
 
 // Push form over a plan: item = ((b*chunks + c) * N + n); the input row is loaded once and stored to
-// every output row of its segment.
+// every output row of its segment (PU positions fetched per step so the stores issue back to back).
+template <bool NT_LD, bool NT_ST, int PU>
 __global__ __launch_bounds__(256) void select_rows_push_kernel(const char* __restrict__ in,
                                                                const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ perm, char* __restrict__ out,
@@ -70,11 +74,15 @@ __global__ __launch_bounds__(256) void select_rows_push_kernel(const char* __res
         if (colb >= rowbytes) continue;
         const int32_t beg = rowptr[n], end = rowptr[n + 1];
         if (beg == end) continue;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(in + (b * N + n) * rowbytes + colb);
+        const u32x4 v = load16<NT_LD>(in + (b * N + n) * rowbytes + colb);
         char* outb = out + (b * E) * rowbytes + colb;
-        for (int32_t j = beg; j < end; ++j) {
-            const int64_t e = perm[j];
-            *reinterpret_cast<u32x4*>(outb + e * rowbytes) = v;
+        for (int32_t j = beg; j < end; j += PU) {
+            int32_t e[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) e[u] = (j + u < end) ? perm[j + u] : -1;
+#pragma unroll
+            for (int u = 0; u < PU; ++u)
+                if (e[u] >= 0) store16<NT_ST>(outb + (int64_t)e[u] * rowbytes, v);
         }
     }
 }
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void select_sum_rows_kernel(const T* __restric
         u32x4 v[ROWS_IN_FLIGHT];
 #pragma unroll
         for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
-            if (p[u]) v[u] = *reinterpret_cast<const u32x4*>(p[u]);
+            if (p[u]) v[u] = load16<true>(p[u]);
 #pragma unroll
         for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
             if (p[u]) {
@@ -221,9 +229,11 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
     if (rowbytes % 16 == 0 && (uintptr_t)input % 16 == 0 && (uintptr_t)out % 16 == 0) {
         RowGeom g = row_geom(rowbytes / 16);
         const int64_t items = B * g.chunks * E;
-        int grid = gnnops_grid_cap(gnnops_cdiv(items, (256 >> g.gshift) * ROWS_IN_FLIGHT), 256 * 32);
-        hipLaunchKernelGGL(select_rows_kernel, dim3(grid), dim3(256), 0, stream, (const char*)input, index, (char*)out,
-                           B, N, E, rowbytes, g.gshift, g.chunks);
+        // nontemporal on both sides, 4 rows in flight per lane group, 64 workgroups per CU of grid:
+        // the fastest of the variants swept with tools/time_sel.py at config 2
+        const int sgrid = gnnops_grid_cap(gnnops_cdiv(items, (256 >> g.gshift) * ROWS_IN_FLIGHT), 256 * 64);
+        hipLaunchKernelGGL((select_rows_kernel<true, true, ROWS_IN_FLIGHT>), dim3(sgrid), dim3(256), 0, stream,
+                           (const char*)input, index, (char*)out, B, N, E, rowbytes, g.gshift, g.chunks);
     } else {
         int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
         if (elem_bytes == 4)
@@ -250,9 +260,9 @@ extern "C" int gnnops_index_select_planned(const void* input, const int32_t* row
                    "index_select_planned: rows must be 16-byte multiples and 16-byte aligned");
     RowGeom g = row_geom(rowbytes / 16);
     const int64_t items = B * g.chunks * N;
-    int grid = gnnops_grid_cap(gnnops_cdiv(items, 256 >> g.gshift), 256 * 32);
-    hipLaunchKernelGGL(select_rows_push_kernel, dim3(grid), dim3(256), 0, stream, (const char*)input, rowptr, perm,
-                       (char*)out, B, N, E, rowbytes, g.gshift, g.chunks);
+    const int grid = gnnops_grid_cap(gnnops_cdiv(items, 256 >> g.gshift), 256 * 64);
+    hipLaunchKernelGGL((select_rows_push_kernel<true, true, 8>), dim3(grid), dim3(256), 0, stream, (const char*)input,
+                       rowptr, perm, (char*)out, B, N, E, rowbytes, g.gshift, g.chunks);
     return gnnops_check_launch("index_select_planned");
 }
 

@@ -15,7 +15,10 @@
 
 namespace {
 
-constexpr int UNROLL = 8;  // contribution rows in flight per lane group
+constexpr int U = 8;       // contribution rows in flight per lane group
+// Source rows and output rows are touched exactly once: nontemporal accesses keep them from evicting
+// rowptr / perm lines (measured -5 % kernel time at config 2; tools/time_seg.py).
+constexpr bool NT = true;
 
 // Row form: the row is K elements, K % VEC == 0, 16-B aligned. A group of G = 2^gshift lanes owns one
 // (b, n, chunk) item; chunk c covers elements [c*G*VEC, (c+1)*G*VEC).
@@ -56,16 +59,16 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
 #pragma unroll
         for (int v = 0; v < VEC; ++v) arg[v] = (int32_t)E;
 
-        for (int32_t j = beg; j < end; j += UNROLL) {
-            int32_t e[UNROLL];
-            u32x4 rows[UNROLL];
+        for (int32_t j = beg; j < end; j += U) {
+            int32_t e[U];
+            u32x4 rows[U];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) e[u] = (j + u < end) ? perm[j + u] : -1;
+            for (int u = 0; u < U; ++u) e[u] = (j + u < end) ? perm[j + u] : -1;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                if (e[u] >= 0) rows[u] = *reinterpret_cast<const u32x4*>(srcb + (int64_t)e[u] * K);
+            for (int u = 0; u < U; ++u)
+                if (e[u] >= 0) rows[u] = load16<NT>(srcb + (int64_t)e[u] * K);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < U; ++u) {
                 if (e[u] >= 0) {
                     float f[VEC];
                     Elem<T>::unpack(rows[u], f);
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
                 for (int v = 0; v < VEC; ++v) acc[v] = acc[v] / c;
             }
         }
-        *reinterpret_cast<u32x4*>(out + oidx) = Elem<T>::pack(acc);
+        store16<NT>(out + oidx, Elem<T>::pack(acc));
     }
 }
 
@@ -161,7 +164,7 @@ int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void
         const int kchunks = (int)gnnops_cdiv(vecs, G);
         const int64_t items = B * kchunks * N;
         const int64_t groups_per_block = 256 >> gshift;
-        int grid = gnnops_grid_cap(gnnops_cdiv(items, groups_per_block), 256 * 32);
+        int grid = gnnops_grid_cap(gnnops_cdiv(items, groups_per_block), 256 * 64);
         hipLaunchKernelGGL((seg_rows_kernel<T, R>), dim3(grid), dim3(256), 0, stream, (const T*)src, rowptr, perm,
                            (T*)out, arg_out, B, E, K, N, gshift, kchunks, init_from_out, is_mean);
     } else {

@@ -5,9 +5,9 @@
 
 namespace sortengine {
 
-constexpr int THREADS = 256;
+constexpr int THREADS = 512;
 constexpr int WAVES = THREADS / 64;
-constexpr int ROUNDS = 32;
+constexpr int ROUNDS = 16;
 constexpr int TILE = WAVES * ROUNDS * 64;  // 8192 keys per workgroup
 constexpr int RADIX = 256;
 

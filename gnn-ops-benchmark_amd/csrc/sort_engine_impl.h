@@ -3,19 +3,25 @@
 // One pass = three launches:
 //   hist_kernel     grid = tiles        per-tile digit histogram -> tile_hist[digit][tile]
 //   scan_kernel     grid = 256 digits   exclusive scan of tile_hist[digit][*], digit totals
-//   scatter_kernel  grid = tiles        stable rank of every key inside its tile (wave ballots +
-//                                       per-wave LDS counters), reorder through LDS, then write each
-//                                       digit's run to its global position (runs are contiguous, so
-//                                       stores coalesce)
-// Keys are processed as u32 digits of a u32 or u64 key; values are u32 (positions < 2^32).
-// Tile = 4 waves x 32 rows x 64 lanes = 8192 keys: 64 KiB of LDS for the reorder buffers, two
-// workgroups per CU.
+//   scatter_kernel  grid = tiles        stable rank of every key inside its tile, reorder through LDS,
+//                                       then write each digit's run to its global position (runs are
+//                                       contiguous, so stores coalesce)
+// Ranking (scatter_kernel phase 1): each wave owns 16 consecutive rows of 64 keys. Per row, eight
+// ballots give every lane the mask of lanes holding the same digit; the lowest such lane adds the group
+// size to the wave's LDS counter with ONE returning ds_add per distinct digit, and the others fetch the
+// returned base with a bpermute. The 16 rows' atomics are issued back to back (LDS executes a wave's
+// operations in order, so row r+1 sees row r's add) and consumed afterwards, so no row waits on LDS.
+// Keys are u32 or u64 with an 8-bit digit taken at `shift`; values are u32 (positions < 2^32).
+// Tile = 8 waves x 16 rows x 64 lanes = 8192 keys; 64 KiB of LDS for the (key, value) reorder image
+// (u32 keys), two workgroups = 16 waves per CU.
 #pragma once
 #include "common.h"
 #include "sort_engine.h"
 
 namespace sortengine {
 
+constexpr int HIST_THREADS = 256;
+constexpr int HIST_WAVES = HIST_THREADS / 64;
 
 // --- key adapters: how a stored key yields the current 8-bit digit and how it is carried ---
 struct KeyI64Low32 {  // first pass of the plan builder: int64 index -> u32 key
@@ -37,13 +43,13 @@ struct KeyU64 {
     __device__ static inline uint32_t digit(Carry k, int shift) { return (uint32_t)(k >> shift) & 255u; }
 };
 // torch.sort on fp32: order-preserving map float -> u32 (negatives flipped entirely, positives get the
-// sign bit); NaNs sort last like torch (they map above +inf because their payload is non-zero).
+// sign bit); NaNs sort last like torch (any NaN maps to the top key).
 struct KeyF32 {
     using In = float;
     using Carry = uint32_t;
     __device__ static inline Carry load(const In* p, int64_t i) {
         uint32_t u = __float_as_uint(p[i]);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // any NaN -> top key
+        if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
         return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     }
     __device__ static inline uint32_t digit(Carry k, int shift) { return (k >> shift) & 255u; }
@@ -59,7 +65,8 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-// Exclusive scan of one value per thread over a 256-thread block. s_tmp: WAVES words of LDS.
+// Exclusive scan of one value per thread over an NW-wave block. s_tmp: NW words of LDS.
+template <int NW>
 __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = wave_incl_scan(v);
@@ -67,7 +74,7 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp, uint32_t
     __syncthreads();
     uint32_t off = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
+    for (int w = 0; w < NW; ++w) {
         uint32_t t = s_tmp[w];
         if (w < wave) off += t;
         tot += t;
@@ -78,34 +85,43 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp, uint32_t
 }
 
 template <typename KA>
-__global__ __launch_bounds__(THREADS) void hist_kernel(const typename KA::In* __restrict__ keys, int64_t n, int shift,
-                                                       uint32_t* __restrict__ tile_hist, int num_tiles) {
-    __shared__ uint32_t h[WAVES][RADIX];
+__global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const typename KA::In* __restrict__ keys, int64_t n,
+                                                            int shift, uint32_t* __restrict__ tile_hist,
+                                                            int num_tiles) {
+    __shared__ uint32_t h[HIST_WAVES][RADIX];
     const int tid = threadIdx.x, wave = tid >> 6;
-    for (int i = tid; i < WAVES * RADIX; i += THREADS) (&h[0][0])[i] = 0;
+    for (int i = tid; i < HIST_WAVES * RADIX; i += HIST_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * TILE;
-    const int64_t lim = (n - base < TILE) ? (n - base) : TILE;
-#pragma unroll 8
-    for (int i = tid; i < lim; i += THREADS) {
-        uint32_t d = KA::digit(KA::load(keys, base + i), shift);
-        atomicAdd(&h[wave][d], 1u);
+    const int lim = (int)((n - base < TILE) ? (n - base) : TILE);
+    // four consecutive keys per lane (16 B for u32 keys): TILE and `base` are multiples of 4
+#pragma unroll 2
+    for (int i = tid * 4; i < lim; i += HIST_THREADS * 4) {
+        if (i + 3 < lim) {
+            typename KA::Carry k[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[j] = KA::load(keys, base + i + j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(&h[wave][KA::digit(k[j], shift)], 1u);
+        } else {
+            for (int j = i; j < lim; ++j) atomicAdd(&h[wave][KA::digit(KA::load(keys, base + j), shift)], 1u);
+        }
     }
     __syncthreads();
     uint32_t t = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) t += h[w][tid];
+    for (int w = 0; w < HIST_WAVES; ++w) t += h[w][tid];
     tile_hist[(size_t)tid * num_tiles + blockIdx.x] = t;
 }
 
 // One block per digit: in-place exclusive scan across tiles, total -> digit_total[digit].
-__global__ __launch_bounds__(THREADS) void scan_kernel(uint32_t* __restrict__ tile_hist, int num_tiles,
-                                                       uint32_t* __restrict__ digit_total) {
-    __shared__ uint32_t s_tmp[WAVES];
+__global__ __launch_bounds__(HIST_THREADS) void scan_kernel(uint32_t* __restrict__ tile_hist, int num_tiles,
+                                                            uint32_t* __restrict__ digit_total) {
+    __shared__ uint32_t s_tmp[HIST_WAVES];
     uint32_t* row = tile_hist + (size_t)blockIdx.x * num_tiles;
     uint32_t carry = 0;
     constexpr int IPT = 8;
-    for (int base = 0; base < num_tiles; base += THREADS * IPT) {
+    for (int base = 0; base < num_tiles; base += HIST_THREADS * IPT) {
         uint32_t v[IPT];
         uint32_t sum = 0;
         const int i0 = base + threadIdx.x * IPT;
@@ -115,7 +131,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(uint32_t* __restrict__ ti
             sum += v[j];
         }
         uint32_t tot;
-        uint32_t off = carry + block_excl_scan(sum, s_tmp, &tot);
+        uint32_t off = carry + block_excl_scan<HIST_WAVES>(sum, s_tmp, &tot);
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             if (i0 + j < num_tiles) row[i0 + j] = off;
@@ -127,19 +143,21 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(uint32_t* __restrict__ ti
 }
 
 template <typename KA, bool IMPLICIT_VALS, bool WRITE_KEYS>
-__global__ __launch_bounds__(THREADS) void scatter_kernel(const typename KA::In* __restrict__ keys_in,
+__global__ __launch_bounds__(THREADS, (sizeof(typename KA::Carry) == 4 ? 4 : 2)) void scatter_kernel(const typename KA::In* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ vals_in,
                                                           typename KA::Carry* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out, int64_t n, int shift,
                                                           const uint32_t* __restrict__ tile_hist_scanned,
                                                           const uint32_t* __restrict__ digit_total, int num_tiles) {
     using Carry = typename KA::Carry;
-    __shared__ Carry s_keys[TILE];
-    __shared__ uint32_t s_vals[TILE];
+    constexpr bool PACKED = sizeof(Carry) == 4;  // (value << 32 | key) in one 8-byte LDS slot
+    __shared__ __attribute__((aligned(16))) unsigned char s_image[TILE * (sizeof(Carry) + 4)];
     __shared__ uint32_t s_whist[WAVES][RADIX];
-    __shared__ uint32_t s_tile_start[RADIX];
     __shared__ uint32_t s_glob[RADIX];
     __shared__ uint32_t s_tmp[WAVES];
+    uint64_t* s_pairs = reinterpret_cast<uint64_t*>(s_image);                          // PACKED
+    Carry* s_keys = reinterpret_cast<Carry*>(s_image);                                 // !PACKED
+    uint32_t* s_vals = reinterpret_cast<uint32_t*>(s_image + TILE * sizeof(Carry));    // !PACKED
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s_whist[0][0])[i] = 0;
@@ -148,19 +166,27 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const typename KA::In*
     const int64_t base = (int64_t)blockIdx.x * TILE;
     const int64_t wave_base = base + (int64_t)wave * ROUNDS * 64;
     const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t* whist = &s_whist[wave][0];
 
     Carry key[ROUNDS];
-    uint32_t rank[ROUNDS];
-    volatile uint32_t* whist = &s_whist[wave][0];
+    uint32_t val[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int64_t i = wave_base + r * 64 + lane;
+        key[r] = (i < n) ? KA::load(keys_in, i) : (Carry)0;
+        if (!IMPLICIT_VALS) val[r] = (i < n) ? vals_in[i] : 0u;
+    }
 
     // Phase 1: stable rank of each key among equal digits of its wave (rows of 64 keys in memory order).
+    // x[r] holds, in a group's lowest lane, the base returned by the LDS add; in the other lanes
+    // `below | leader_lane << 8`. is_leader has bit r set where this lane is row r's group leader.
+    uint32_t x[ROUNDS];
+    uint32_t is_leader = 0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const int64_t i = wave_base + r * 64 + lane;
         const bool valid = i < n;
-        Carry k = valid ? KA::load(keys_in, i) : (Carry)0;
-        key[r] = k;
-        const uint32_t d = KA::digit(k, shift);
+        const uint32_t d = KA::digit(key[r], shift);
         uint64_t m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -169,27 +195,48 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const typename KA::In*
             m &= bit ? bal : ~bal;
         }
         const uint32_t below = __popcll(m & lanes_below);
-        const uint32_t cnt = __popcll(m);
-        const uint32_t prior = whist[d];
-        if (valid && below == 0) whist[d] = prior + cnt;
-        rank[r] = prior + below;
+        if (valid && below == 0) {
+            x[r] = atomicAdd(&whist[d], (uint32_t)__popcll(m));
+            is_leader |= 1u << r;
+        } else {
+            x[r] = below | ((uint32_t)(__ffsll((unsigned long long)m) - 1) << 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep rows from being interleaved (register pressure)
+    }
+    uint32_t rank[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const bool lead = (is_leader >> r) & 1u;
+        const int from = lead ? lane : (int)((x[r] >> 8) & 63u);
+        const uint32_t p = __shfl(x[r], from);
+        rank[r] = lead ? p : p + (x[r] & 255u);
     }
     __syncthreads();
 
-    // Phase 2: per-digit wave offsets, tile-local digit starts, global run bases.
+    // Phase 2: per-digit wave offsets (+ tile-local digit start), global run bases.
     {
-        const int d = tid;
-        uint32_t off = 0;
+        const int d = tid & (RADIX - 1);
+        const bool act = tid < RADIX;
+        uint32_t cnts[WAVES];
+        uint32_t tot = 0;
+        if (act) {
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            uint32_t c = s_whist[w][d];
-            s_whist[w][d] = off;
-            off += c;
+            for (int w = 0; w < WAVES; ++w) {
+                cnts[w] = s_whist[w][d];
+                tot += cnts[w];
+            }
         }
-        uint32_t tile_start = block_excl_scan(off, s_tmp, nullptr);
-        uint32_t digit_base = block_excl_scan(digit_total[d], s_tmp, nullptr);
-        s_tile_start[d] = tile_start;
-        s_glob[d] = digit_base + tile_hist_scanned[(size_t)d * num_tiles + blockIdx.x] - tile_start;
+        const uint32_t tile_start = block_excl_scan<WAVES>(act ? tot : 0u, s_tmp, nullptr);
+        const uint32_t digit_base = block_excl_scan<WAVES>(act ? digit_total[d] : 0u, s_tmp, nullptr);
+        if (act) {
+            uint32_t off = tile_start;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                s_whist[w][d] = off;
+                off += cnts[w];
+            }
+            s_glob[d] = digit_base + tile_hist_scanned[(size_t)d * num_tiles + blockIdx.x] - tile_start;
+        }
     }
     __syncthreads();
 
@@ -199,22 +246,35 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const typename KA::In*
         const int64_t i = wave_base + r * 64 + lane;
         if (i < n) {
             const uint32_t d = KA::digit(key[r], shift);
-            const uint32_t pos = s_tile_start[d] + s_whist[wave][d] + rank[r];
-            s_keys[pos] = key[r];
-            s_vals[pos] = IMPLICIT_VALS ? (uint32_t)i : vals_in[i];
+            const uint32_t pos = whist[d] + rank[r];
+            const uint32_t v = IMPLICIT_VALS ? (uint32_t)i : val[r];
+            if constexpr (PACKED) {
+                s_pairs[pos] = ((uint64_t)v << 32) | (uint64_t)(uint32_t)key[r];
+            } else {
+                s_keys[pos] = key[r];
+                s_vals[pos] = v;
+            }
         }
     }
     __syncthreads();
 
-    // Phase 4: write runs. Position i of the tile-sorted buffer goes to s_glob[digit] + i.
+    // Phase 4: write runs. Position i of the tile-sorted image goes to s_glob[digit] + i.
     const int lim = (int)((n - base < TILE) ? (n - base) : TILE);
 #pragma unroll 4
     for (int i = tid; i < lim; i += THREADS) {
-        const Carry k = s_keys[i];
-        const uint32_t d = KA::digit(k, shift);
-        const uint32_t g = s_glob[d] + (uint32_t)i;
+        Carry k;
+        uint32_t v;
+        if constexpr (PACKED) {
+            const uint64_t p = s_pairs[i];
+            k = (Carry)(uint32_t)p;
+            v = (uint32_t)(p >> 32);
+        } else {
+            k = s_keys[i];
+            v = s_vals[i];
+        }
+        const uint32_t g = s_glob[KA::digit(k, shift)] + (uint32_t)i;
         if (WRITE_KEYS) keys_out[g] = k;
-        vals_out[g] = s_vals[i];
+        vals_out[g] = v;
     }
 }
 
@@ -222,9 +282,9 @@ template <typename KA, bool IMPLICIT_VALS, bool WRITE_KEYS>
 inline int run_pass(const typename KA::In* keys_in, const uint32_t* vals_in, typename KA::Carry* keys_out,
                     uint32_t* vals_out, int64_t n, int shift, uint32_t* tile_hist, uint32_t* digit_total,
                     int num_tiles, hipStream_t stream) {
-    hipLaunchKernelGGL((hist_kernel<KA>), dim3(num_tiles), dim3(THREADS), 0, stream, keys_in, n, shift, tile_hist,
-                       num_tiles);
-    hipLaunchKernelGGL(scan_kernel, dim3(RADIX), dim3(THREADS), 0, stream, tile_hist, num_tiles, digit_total);
+    hipLaunchKernelGGL((hist_kernel<KA>), dim3(num_tiles), dim3(HIST_THREADS), 0, stream, keys_in, n, shift,
+                       tile_hist, num_tiles);
+    hipLaunchKernelGGL(scan_kernel, dim3(RADIX), dim3(HIST_THREADS), 0, stream, tile_hist, num_tiles, digit_total);
     hipLaunchKernelGGL((scatter_kernel<KA, IMPLICIT_VALS, WRITE_KEYS>), dim3(num_tiles), dim3(THREADS), 0, stream,
                        keys_in, vals_in, keys_out, vals_out, n, shift, tile_hist, digit_total, num_tiles);
     return gnnops_check_launch("radix pass");

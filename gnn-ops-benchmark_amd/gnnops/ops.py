@@ -308,9 +308,18 @@ def _elem_bytes(t, what):
     return eb
 
 
+# index_select picks the push form by itself when it pays: the table is far larger than the 256 MiB
+# Infinity Cache (so re-reads of a row go to HBM) and every row is selected several times on average.
+_PUSH_MIN_TABLE_BYTES = 1 << 30
+_PUSH_MIN_REUSE = 3
+
+
 def index_select(input, dim, index, plan=None):
-    """torch.index_select(input, dim, index). With ``plan`` (a Plan of index over input.size(dim)) the push
-    form is used: every input row is read once and stored to all rows that select it."""
+    """torch.index_select(input, dim, index).
+
+    Pull form: one gathered row per output row (E*row random reads). Push form (a Plan of ``index`` over
+    input.size(dim), given or built here when the heuristic above says so): every input row is read once
+    and stored to all output rows that select it — N*row reads instead of E*row."""
     _require_gpu(input, index)
     _check_index(index, "index_select")
     if index.dim() > 1:
@@ -325,6 +334,10 @@ def index_select(input, dim, index, plan=None):
     shape[dim] = E
     out = torch.empty(shape, dtype=input.dtype, device=input.device)
     L = _lib.load()
+    row_bytes = K * eb
+    if (plan is None and row_bytes % 16 == 0 and N * row_bytes * B >= _PUSH_MIN_TABLE_BYTES
+            and E >= _PUSH_MIN_REUSE * N and input.data_ptr() % 16 == 0):
+        plan = get_plan(index, N)
     with torch.cuda.device(input.device):
         if plan is not None:
             if plan.E != E or plan.N != N:
