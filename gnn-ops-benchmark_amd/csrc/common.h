@@ -140,3 +140,31 @@ template <> struct Red<GNNOPS_MAX> {
 };
 
 __device__ static inline int lane_id() { return threadIdx.x & 63; }
+
+// ---- block-level exclusive scan of one u32 per thread (NW waves); s_tmp: NW words of LDS ----
+__device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+template <int NW>
+__device__ inline uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(v);
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        uint32_t t = s_tmp[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return off + incl - v;
+}

@@ -49,40 +49,12 @@ struct KeyF32 {
     using Carry = uint32_t;
     __device__ static inline Carry load(const In* p, int64_t i) {
         uint32_t u = __float_as_uint(p[i]);
+        if (u == 0x80000000u) u = 0u;  // -0.0 compares equal to +0.0
         if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
         return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     }
     __device__ static inline uint32_t digit(Carry k, int shift) { return (k >> shift) & 255u; }
 };
-
-__device__ inline uint32_t wave_incl_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-
-// Exclusive scan of one value per thread over an NW-wave block. s_tmp: NW words of LDS.
-template <int NW>
-__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = wave_incl_scan(v);
-    if (lane == 63) s_tmp[wave] = incl;
-    __syncthreads();
-    uint32_t off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        uint32_t t = s_tmp[w];
-        if (w < wave) off += t;
-        tot += t;
-    }
-    __syncthreads();
-    if (total) *total = tot;
-    return off + incl - v;
-}
 
 template <typename KA>
 __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const typename KA::In* __restrict__ keys, int64_t n,
@@ -131,7 +103,7 @@ __global__ __launch_bounds__(HIST_THREADS) void scan_kernel(uint32_t* __restrict
             sum += v[j];
         }
         uint32_t tot;
-        uint32_t off = carry + block_excl_scan<HIST_WAVES>(sum, s_tmp, &tot);
+        uint32_t off = carry + block_excl_scan_u32<HIST_WAVES>(sum, s_tmp, &tot);
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             if (i0 + j < num_tiles) row[i0 + j] = off;
@@ -226,8 +198,8 @@ __global__ __launch_bounds__(THREADS, (sizeof(typename KA::Carry) == 4 ? 4 : 2))
                 tot += cnts[w];
             }
         }
-        const uint32_t tile_start = block_excl_scan<WAVES>(act ? tot : 0u, s_tmp, nullptr);
-        const uint32_t digit_base = block_excl_scan<WAVES>(act ? digit_total[d] : 0u, s_tmp, nullptr);
+        const uint32_t tile_start = block_excl_scan_u32<WAVES>(act ? tot : 0u, s_tmp, nullptr);
+        const uint32_t digit_base = block_excl_scan_u32<WAVES>(act ? digit_total[d] : 0u, s_tmp, nullptr);
         if (act) {
             uint32_t off = tile_start;
 #pragma unroll

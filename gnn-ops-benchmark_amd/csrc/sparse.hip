@@ -1,0 +1,229 @@
+// sparse.hip — COO housekeeping: torch_sparse.coalesce / Tensor.coalesce()
+// (reference: op_bm_scripts/benchmark_sparse_coalesce.py:35-42), torch_sparse.transpose (= swap + coalesce;
+// data/sparse_transpose.csv) and the dense `transpose(0,1).contiguous()` the current script times
+// (benchmark_sparse_transpose.py:13-16).
+//
+// coalesce: sort entries by key = row*n + col with the radix engine (stable, 64-bit keys, only the bytes
+// the key range needs), mark the first entry of every distinct key, compact (row, col) and reduce the
+// values of each run in sorted order (fp32 accumulation, one rounding). The number of distinct keys is
+// data dependent: outputs are sized nnz and the count is left in device memory for the caller.
+// All phases are HBM-bound index work (8-16 B per entry per pass).
+#include "common.h"
+#include "sort_engine.h"
+
+namespace {
+
+#define GRID_STRIDE(i, total) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_IPT = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_IPT;
+
+__global__ void build_coo_keys_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                      uint64_t* __restrict__ keys, int64_t nnz, int64_t n) {
+    GRID_STRIDE(i, nnz) keys[i] = (uint64_t)(row[i] * n + col[i]);
+}
+
+__device__ inline bool is_head(const uint64_t* keys, int64_t p) { return p == 0 || keys[p] != keys[p - 1]; }
+
+__global__ __launch_bounds__(SCAN_THREADS) void count_heads_kernel(const uint64_t* __restrict__ keys, int64_t nnz,
+                                                                   uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_tmp[SCAN_THREADS / 64];
+    const int64_t p0 = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; ++j)
+        if (p0 + j < nnz && is_head(keys, p0 + j)) ++c;
+    uint32_t tot;
+    block_excl_scan_u32<SCAN_THREADS / 64>(c, s_tmp, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block_sums in place, total -> *d_count (int64)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint32_t* __restrict__ block_sums, int nb,
+                                                                 int64_t* __restrict__ d_count) {
+    __shared__ uint32_t s_tmp[SCAN_THREADS / 64];
+    uint32_t carry = 0;
+    for (int base = 0; base < nb; base += SCAN_THREADS) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nb ? block_sums[i] : 0u;
+        uint32_t tot;
+        const uint32_t off = carry + block_excl_scan_u32<SCAN_THREADS / 64>(v, s_tmp, &tot);
+        if (i < nb) block_sums[i] = off;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *d_count = (int64_t)carry;
+}
+
+// compact: for every head at sorted position p with rank u: out_row[u], out_col[u], seg_start[u] = p.
+__global__ __launch_bounds__(SCAN_THREADS) void emit_heads_kernel(const uint64_t* __restrict__ keys, int64_t nnz,
+                                                                  int64_t n, const uint32_t* __restrict__ block_off,
+                                                                  int64_t* __restrict__ out_row,
+                                                                  int64_t* __restrict__ out_col,
+                                                                  uint32_t* __restrict__ seg_start) {
+    __shared__ uint32_t s_tmp[SCAN_THREADS / 64];
+    const int64_t p0 = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
+    bool h[SCAN_IPT];
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; ++j) {
+        h[j] = (p0 + j < nnz) && is_head(keys, p0 + j);
+        c += h[j];
+    }
+    uint32_t u = block_off[blockIdx.x] + block_excl_scan_u32<SCAN_THREADS / 64>(c, s_tmp, nullptr);
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; ++j) {
+        if (h[j]) {
+            const uint64_t k = keys[p0 + j];
+            out_row[u] = (int64_t)(k / (uint64_t)n);
+            out_col[u] = (int64_t)(k % (uint64_t)n);
+            seg_start[u] = (uint32_t)(p0 + j);
+            ++u;
+        }
+    }
+}
+
+// out_value[u, c] = sum over sorted positions of run u, in order, of value[perm[p], c]
+template <typename T>
+__global__ void reduce_runs_kernel(const T* __restrict__ value, const uint32_t* __restrict__ perm,
+                                   const uint32_t* __restrict__ seg_start, const int64_t* __restrict__ d_count,
+                                   T* __restrict__ out_value, int64_t nnz, int64_t C) {
+    const int64_t count = *d_count;
+    GRID_STRIDE(o, count * C) {
+        const int64_t u = o / C, c = o % C;
+        const int64_t beg = seg_start[u];
+        const int64_t end = (u + 1 < count) ? (int64_t)seg_start[u + 1] : nnz;
+        float acc = 0.f;
+        for (int64_t p = beg; p < end; ++p) acc = __fadd_rn(acc, Elem<T>::load(value + (int64_t)perm[p] * C + c));
+        Elem<T>::store(out_value + o, acc);
+    }
+}
+
+// ---- dense 2-D transpose through a padded LDS tile (64 x 64 elements, conflict-free column reads) ----
+template <typename U>
+__global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in, U* __restrict__ out, int64_t R,
+                                                        int64_t C) {
+    __shared__ U tile[64][64 + (4 / sizeof(U) > 0 ? 4 / sizeof(U) : 1)];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t r = r0 + ty + 4 * j, c = c0 + tx;
+        if (r < R && c < C) tile[ty + 4 * j][tx] = in[r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t c = c0 + ty + 4 * j, r = r0 + tx;
+        if (r < R && c < C) out[c * R + r] = tile[tx][ty + 4 * j];
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int grid_for(int64_t n) { return gnnops_grid_cap(gnnops_cdiv(n, 256), 256 * 16); }
+
+int key_bytes_for(int64_t m, int64_t n) {
+    // number of 8-bit passes that cover keys in [0, m*n)
+    unsigned __int128 range = (unsigned __int128)(m > 0 ? m : 1) * (unsigned __int128)(n > 0 ? n : 1);
+    int bytes = 1;
+    while (bytes < 8 && (range - 1) >> (8 * bytes)) ++bytes;
+    return bytes;
+}
+
+}  // namespace
+
+// workspace: keys_a[nnz] u64 | keys_b[nnz] u64 | vals_a[nnz] u32 | vals_b[nnz] u32 | tile_hist | digit_total |
+//            block_sums[ceil(nnz/2048)] u32 | seg_start[nnz] u32
+extern "C" size_t gnnops_coalesce_workspace_bytes(int64_t nnz) {
+    if (nnz < 0) return 0;
+    const size_t n = (size_t)nnz;
+    const size_t tiles = (size_t)gnnops_cdiv(nnz > 0 ? nnz : 1, sortengine::TILE);
+    const size_t nb = (size_t)gnnops_cdiv(nnz > 0 ? nnz : 1, SCAN_TILE);
+    return 2 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + align_up(256 * tiles * 4, 256) + 1024 +
+           align_up(nb * 4, 256) + align_up(n * 4, 256);
+}
+
+extern "C" int gnnops_coalesce(const int64_t* row, const int64_t* col, const void* value, int64_t nnz, int64_t m,
+                               int64_t n, int64_t C, int dtype, int64_t* out_row, int64_t* out_col, void* out_value,
+                               int64_t* d_count, void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(nnz >= 0 && m >= 0 && n >= 0 && C >= 0, GNNOPS_EINVAL, "coalesce: negative size");
+    GNNOPS_REQUIRE(nnz < ((int64_t)1 << 32), GNNOPS_EUNSUPPORTED, "coalesce: nnz must be < 2^32");
+    GNNOPS_REQUIRE(d_count != nullptr, GNNOPS_EINVAL, "coalesce: d_count is null");
+    if (nnz == 0) {
+        if (hipMemsetAsync(d_count, 0, sizeof(int64_t), stream) != hipSuccess) return gnnops_check_launch("coalesce memset");
+        return GNNOPS_OK;
+    }
+    GNNOPS_REQUIRE(row && col && out_row && out_col, GNNOPS_EINVAL, "coalesce: null pointer");
+    GNNOPS_REQUIRE(value == nullptr || out_value != nullptr, GNNOPS_EINVAL, "coalesce: value given without out_value");
+    GNNOPS_REQUIRE(workspace && workspace_bytes >= gnnops_coalesce_workspace_bytes(nnz), GNNOPS_EWORKSPACE,
+                   "coalesce: workspace %zu < %zu", workspace_bytes, gnnops_coalesce_workspace_bytes(nnz));
+    const int tiles = (int)gnnops_cdiv(nnz, sortengine::TILE);
+    const int nb = (int)gnnops_cdiv(nnz, SCAN_TILE);
+    char* w = (char*)workspace;
+    uint64_t* keys_a = (uint64_t*)w; w += align_up((size_t)nnz * 8, 256);
+    uint64_t* keys_b = (uint64_t*)w; w += align_up((size_t)nnz * 8, 256);
+    uint32_t* vals_a = (uint32_t*)w; w += align_up((size_t)nnz * 4, 256);
+    uint32_t* vals_b = (uint32_t*)w; w += align_up((size_t)nnz * 4, 256);
+    uint32_t* tile_hist = (uint32_t*)w; w += align_up((size_t)256 * tiles * 4, 256);
+    uint32_t* digit_total = (uint32_t*)w; w += 1024;
+    uint32_t* block_sums = (uint32_t*)w; w += align_up((size_t)nb * 4, 256);
+    uint32_t* seg_start = (uint32_t*)w;
+
+    hipLaunchKernelGGL(build_coo_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, stream, row, col, keys_b, nnz, n);
+    const int passes = key_bytes_for(m, n);
+    uint64_t* kin = keys_b;
+    uint64_t* kout = keys_a;
+    uint32_t* vin = nullptr;
+    uint32_t* vout = vals_a;
+    for (int p = 0; p < passes; ++p) {
+        int rc = (p == 0) ? sortengine::pass_first_u64(kin, kout, vout, nnz, 0, tile_hist, digit_total, tiles, stream)
+                          : sortengine::pass_u64(kin, vin, kout, vout, nnz, 8 * p, tile_hist, digit_total, tiles, stream);
+        if (rc) return rc;
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* nv = (vout == vals_a) ? vals_b : vals_a;
+        vin = vout; vout = nv;
+    }
+    // kin / vin: sorted keys and the permutation
+    hipLaunchKernelGGL(count_heads_kernel, dim3(nb), dim3(SCAN_THREADS), 0, stream, kin, nnz, block_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, block_sums, nb, d_count);
+    hipLaunchKernelGGL(emit_heads_kernel, dim3(nb), dim3(SCAN_THREADS), 0, stream, kin, nnz, n, block_sums, out_row,
+                       out_col, seg_start);
+    if (value && C > 0) {
+        const int grid = grid_for(nnz * C);
+        switch (dtype) {
+            case GNNOPS_F32:
+                hipLaunchKernelGGL((reduce_runs_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)value, vin,
+                                   seg_start, d_count, (float*)out_value, nnz, C);
+                break;
+            case GNNOPS_F16:
+                hipLaunchKernelGGL((reduce_runs_kernel<__half>), dim3(grid), dim3(256), 0, stream, (const __half*)value, vin,
+                                   seg_start, d_count, (__half*)out_value, nnz, C);
+                break;
+            case GNNOPS_BF16:
+                hipLaunchKernelGGL((reduce_runs_kernel<__hip_bfloat16>), dim3(grid), dim3(256), 0, stream,
+                                   (const __hip_bfloat16*)value, vin, seg_start, d_count, (__hip_bfloat16*)out_value, nnz, C);
+                break;
+            default:
+                gnnops_set_error("coalesce: unknown dtype %d", dtype);
+                return GNNOPS_EINVAL;
+        }
+    }
+    return gnnops_check_launch("coalesce");
+}
+
+extern "C" int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(R >= 0 && C >= 0, GNNOPS_EINVAL, "transpose2d: negative size");
+    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "transpose2d: elem_bytes %d", elem_bytes);
+    if (R * C == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(in && out, GNNOPS_EINVAL, "transpose2d: null pointer");
+    GNNOPS_REQUIRE(gnnops_cdiv(R, 64) < 65536, GNNOPS_EUNSUPPORTED, "transpose2d: too many rows");
+    dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64));
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL((transpose_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, R, C);
+    else
+        hipLaunchKernelGGL((transpose_kernel<uint32_t>), grid, dim3(256), 0, stream, (const uint32_t*)in, (uint32_t*)out, R, C);
+    return gnnops_check_launch("transpose2d");
+}

@@ -28,11 +28,14 @@ from .ops import (
     scatter_sum,
     set_plan_cache,
 )
+from .sparse import (coalesce, coalesce_sparse_tensor, sort, sparse_mm, spmm, spmm_csr, transpose,
+                     transpose_contiguous)
 from .aten import install, uninstall, installed
 
 __all__ = [
     "GnnopsError", "LIB_PATH", "load_library", "Plan", "clear_plan_cache", "gather", "get_plan", "index_add",
     "index_add_", "index_max", "index_select", "index_select_sum", "scatter", "scatter_add", "scatter_add_",
     "scatter_max", "scatter_mean", "scatter_min", "scatter_mul", "scatter_reduce_mul_", "scatter_sum",
-    "set_plan_cache", "install", "uninstall", "installed",
+    "set_plan_cache", "install", "uninstall", "installed", "coalesce", "coalesce_sparse_tensor", "sort", "sparse_mm",
+    "spmm", "spmm_csr", "transpose", "transpose_contiguous",
 ]

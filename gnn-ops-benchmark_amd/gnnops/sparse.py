@@ -1,0 +1,162 @@
+"""Sparse / sort front end: torch_sparse.{spmm, coalesce, transpose}, torch.sparse.mm(COO, dense),
+Tensor.coalesce(), torch.sort and the dense transpose copy — reference call sites:
+op_bm_scripts/benchmark_sparse_spmm.py:12-14, benchmark_sparse_coalesce.py:35-42,
+benchmark_sparse_transpose.py:13-16, benchmark_native_sort.py:28-30.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import Plan, _check_index, _dtype_code, _norm_dim, _bek, _require_gpu, _stream, get_plan
+
+
+def _coo_rows_cols(index, what):
+    _check_index(index, what)
+    if index.dim() != 2 or index.size(0) != 2:
+        raise ValueError(f"{what}: index must have shape [2, nnz]")
+    index = index.contiguous()
+    return index, index[0], index[1]
+
+
+def spmm(index, value, m, n, matrix):
+    """torch_sparse.spmm(index, value, m, n, matrix): (m x n sparse) @ (n x D dense) -> m x D."""
+    _require_gpu(index, value, matrix)
+    index, row, col = _coo_rows_cols(index, "spmm")
+    if matrix.dim() == 1:
+        return spmm(index, value, m, n, matrix.unsqueeze(-1)).squeeze(-1)
+    if matrix.dim() != 2:
+        raise NotImplementedError("gnnops.spmm: matrix must be 1-D or 2-D")
+    if matrix.size(0) != n:
+        raise RuntimeError(f"spmm: matrix has {matrix.size(0)} rows, sparse operand has n={n} columns")
+    dt = _dtype_code(matrix, "spmm")
+    if value is not None and value.dtype != matrix.dtype:
+        raise RuntimeError("spmm: value and matrix must have the same dtype")
+    matrix = matrix.contiguous()
+    plan = get_plan(row, m)  # COO -> CSR view (rowptr, perm), stable
+    return _spmm_launch(plan.rowptr, plan.perm, col, value, matrix, m, dt)
+
+
+def spmm_csr(rowptr, col, value, matrix):
+    """CSR x dense (BASELINE config 3's layout): rowptr int32/int64 [M+1], col int64 [nnz], value [nnz] or None."""
+    _require_gpu(rowptr, col, value, matrix)
+    _check_index(col, "spmm_csr")
+    if rowptr.dtype == torch.int64:
+        rowptr = rowptr.to(torch.int32)  # kernel ABI is int32 row pointers (nnz < 2^31)
+    elif rowptr.dtype != torch.int32:
+        raise RuntimeError("spmm_csr: rowptr must be int32 or int64")
+    dt = _dtype_code(matrix, "spmm_csr")
+    return _spmm_launch(rowptr.contiguous(), None, col.contiguous(), value, matrix.contiguous(), rowptr.numel() - 1, dt)
+
+
+def _spmm_launch(rowptr, perm, col, value, matrix, m, dt):
+    D = matrix.size(1)
+    out = torch.empty((m, D), dtype=matrix.dtype, device=matrix.device)
+    value_c = value.contiguous() if value is not None else None
+    with torch.cuda.device(matrix.device):
+        rc = _lib.load().gnnops_spmm(rowptr.data_ptr(), perm.data_ptr() if perm is not None else None, col.data_ptr(),
+                                     value_c.data_ptr() if value_c is not None else None, matrix.data_ptr(),
+                                     out.data_ptr(), m, D, col.numel(), dt, _stream())
+    check(rc, "spmm")
+    return out
+
+
+def sparse_mm(mat_a, mat_b):
+    """torch.sparse.mm(sparse COO [m,n], dense [n,D]) -> dense [m,D] (benchmark_sparse_spmm.py:12-14)."""
+    if not mat_a.is_sparse:
+        raise RuntimeError("sparse_mm: first operand must be a sparse COO tensor")
+    if mat_b.is_sparse:
+        raise NotImplementedError("gnnops.sparse_mm: sparse x sparse goes through spspmm")
+    m, n = mat_a.shape
+    return spmm(mat_a._indices(), mat_a._values(), m, n, mat_b)
+
+
+def coalesce(index, value, m, n, op="add"):
+    """torch_sparse.coalesce(index, value, m, n, op): row-major sorted, duplicates summed. Synchronises once
+    to learn the number of distinct entries (it sizes the outputs), as the upstream op does."""
+    if op not in ("add", "sum"):
+        raise NotImplementedError(f"gnnops.coalesce: op={op!r} is not supported")
+    _require_gpu(index, value)
+    index, row, col = _coo_rows_cols(index, "coalesce")
+    nnz = index.size(1)
+    L = _lib.load()
+    dev = index.device
+    dt, C, value_c = 0, 0, None
+    if value is not None:
+        if value.size(0) != nnz:
+            raise RuntimeError("coalesce: value.size(0) must equal index.size(1)")
+        dt = _dtype_code(value, "coalesce")
+        value_c = value.contiguous()
+        C = value_c.numel() // max(nnz, 1) if nnz else 0
+    out_index = torch.empty((2, nnz), dtype=torch.int64, device=dev)
+    out_value = torch.empty_like(value_c) if value_c is not None else None
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    ws_bytes = L.gnnops_coalesce_workspace_bytes(nnz)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.gnnops_coalesce(row.data_ptr(), col.data_ptr(), value_c.data_ptr() if value_c is not None else None, nnz,
+                               m, n, C, dt, out_index[0].data_ptr(), out_index[1].data_ptr(),
+                               out_value.data_ptr() if out_value is not None else None, count.data_ptr(),
+                               ws.data_ptr(), ws_bytes, _stream())
+    check(rc, "coalesce")
+    k = int(count.item())
+    return out_index[:, :k], (out_value[:k] if out_value is not None else None)
+
+
+def transpose(index, value, m, n, coalesced=True):
+    """torch_sparse.transpose(index, value, m, n, coalesced): swap rows/cols; coalesce -> sorted by new row."""
+    _require_gpu(index, value)
+    index, row, col = _coo_rows_cols(index, "transpose")
+    swapped = torch.stack([col, row], dim=0)
+    if not coalesced:
+        return swapped, value
+    return coalesce(swapped, value, n, m)
+
+
+def coalesce_sparse_tensor(mat):
+    """Tensor.coalesce() for a sparse COO matrix (benchmark_sparse_coalesce.py:40-42)."""
+    if not mat.is_sparse or mat.sparse_dim() != 2:
+        raise NotImplementedError("gnnops.coalesce_sparse_tensor: 2-D sparse COO tensors only")
+    idx, val = coalesce(mat._indices(), mat._values(), mat.size(0), mat.size(1))
+    out = torch.sparse_coo_tensor(idx, val, mat.shape)
+    return out._coalesced_(True)
+
+
+def transpose_contiguous(mat):
+    """torch.transpose(mat, 0, 1).contiguous() for a dense 2-D tensor (benchmark_sparse_transpose.py:13-16)."""
+    _require_gpu(mat)
+    if mat.dim() != 2:
+        raise NotImplementedError("gnnops.transpose_contiguous: 2-D tensors only")
+    eb = mat.element_size()
+    if eb not in (2, 4):
+        raise NotImplementedError(f"gnnops.transpose_contiguous: element size {eb}")
+    mat = mat.contiguous()
+    R, C = mat.shape
+    out = torch.empty((C, R), dtype=mat.dtype, device=mat.device)
+    with torch.cuda.device(mat.device):
+        rc = _lib.load().gnnops_transpose2d(mat.data_ptr(), out.data_ptr(), R, C, eb, _stream())
+    check(rc, "transpose2d")
+    return out
+
+
+def sort(input, dim=-1, descending=False, stable=False):
+    """torch.sort(input, dim, stable=...) for float32: (values, indices int64), ascending, always stable."""
+    _require_gpu(input)
+    if descending:
+        raise NotImplementedError("gnnops.sort: descending=True is not supported")
+    if input.dtype != torch.float32:
+        raise NotImplementedError(f"gnnops.sort: dtype {input.dtype} is not supported (float32)")
+    if input.dim() == 0:
+        return input.clone(), torch.zeros((), dtype=torch.int64, device=input.device)
+    dim = _norm_dim(dim, input.dim(), "sort")
+    input = input.contiguous()
+    B, E, K = _bek(input.shape, dim)
+    values = torch.empty_like(input)
+    indices = torch.empty(input.shape, dtype=torch.int64, device=input.device)
+    L = _lib.load()
+    ws_bytes = L.gnnops_sort_workspace_bytes(B, E, K)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = L.gnnops_sort_f32(input.data_ptr(), values.data_ptr(), indices.data_ptr(), B, E, K, ws.data_ptr(), ws_bytes,
+                               _stream())
+    check(rc, "sort")
+    return values, indices

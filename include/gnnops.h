@@ -142,6 +142,44 @@ int gnnops_fused_index_select_sum(const void* input, const int64_t* index, float
                                   int dtype, void* workspace, size_t workspace_bytes,
                                   gnnops_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * torch_sparse.spmm(index, value, m, n, matrix) / torch.sparse.mm(COO, dense)
+ * (benchmark_sparse_spmm.py:12-14; BASELINE config 3). Row-split over a CSR view of the sparse operand:
+ *   out[i,:] = sum_{j in [rowptr[i], rowptr[i+1])} value[e_j] * mat[col[e_j], :],  e_j = perm ? perm[j] : j
+ * so a CSR matrix passes perm = NULL and a COO matrix passes the plan of its row index (rowptr, perm).
+ * value == NULL means all ones. mat [n, D], out [M, D]; fp32 accumulation, one rounding.
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_spmm(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value,
+                const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int dtype,
+                gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torch.sort(input, dim, stable) for fp32 (benchmark_native_sort.py:28-30). input viewed [B,E,K],
+ * sorted ascending along E; values fp32 [B,E,K], indices int64 [B,E,K] (position along E). Always
+ * stable. -0.0 is ordered (and returned) as +0.0, NaNs last.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnnops_sort_workspace_bytes(int64_t B, int64_t E, int64_t K);
+int gnnops_sort_f32(const float* input, float* values, int64_t* indices, int64_t B, int64_t E, int64_t K,
+                    void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torch_sparse.coalesce(index, value, m, n, op="add") / Tensor.coalesce()
+ * (benchmark_sparse_coalesce.py:35-42); torch_sparse.transpose = the same call with row/col swapped
+ * and (n, m). Entries are sorted row-major by (row, col); duplicates are summed in sorted (stable)
+ * order. value [nnz, C] of `dtype` or NULL. Outputs are sized nnz; *d_count (device int64) receives
+ * the number of distinct entries.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnnops_coalesce_workspace_bytes(int64_t nnz);
+int gnnops_coalesce(const int64_t* row, const int64_t* col, const void* value, int64_t nnz,
+                    int64_t m, int64_t n, int64_t C, int dtype,
+                    int64_t* out_row, int64_t* out_col, void* out_value, int64_t* d_count,
+                    void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+
+/* Dense 2-D transpose copy: torch.transpose(matA, 0, 1).contiguous() (benchmark_sparse_transpose.py:13-16).
+ * in [R, C] -> out [C, R]; elem_bytes in {2, 4}; bit-exact. */
+int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes,
+                       gnnops_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,3 +236,47 @@ int ora_scatter_add_rows_f32(const float* src, const int64_t* index, float* out,
     }
     return 0;
 }
+
+/*
+ * torch_sparse.spmm restated: out = scatter_add(matrix[col] * value[:,None], row, dim_size=m),
+ * sequential over the entries e = 0..nnz-1. fp32: p = round(v*x) then acc = round(acc+p) (two roundings, as
+ * torch's elementwise multiply followed by scatter_add performs); 16-bit: products are exact in fp32,
+ * accumulated in fp32, rounded once. value == NULL means ones. Reference call site:
+ * op_bm_scripts/benchmark_sparse_spmm.py:12-14 (torch.sparse.mm form).
+ */
+int ora_spmm(const int64_t* row, const int64_t* col, const void* value, const void* mat, void* out, int64_t nnz,
+             int64_t M, int64_t Ncols, int64_t D, int dtype) {
+    float* acc = (float*)calloc((size_t)(M * D > 0 ? M * D : 1), sizeof(float));
+    if (!acc) return 2;
+    for (int64_t e = 0; e < nnz; ++e) {
+        const int64_t r = row[e], c = col[e];
+        if (r < 0 || r >= M || c < 0 || c >= Ncols) { free(acc); return 1; }
+        const float v = value ? ld(value, e, dtype) : 1.0f;
+        for (int64_t k = 0; k < D; ++k) {
+            volatile float p = v * ld(mat, c * D + k, dtype); /* volatile: keep the product rounded, no FMA */
+            acc[r * D + k] = acc[r * D + k] + p;
+        }
+    }
+    for (int64_t i = 0; i < M * D; ++i) st(out, i, dtype, acc[i]);
+    free(acc);
+    return 0;
+}
+
+/*
+ * Run reduction for coalesce: entries already ordered by `perm` (stable sort by row*n+col, done in numpy);
+ * seg_start[u] is the first sorted position of distinct key u. out[u,c] = sum in sorted order (fp32).
+ * Restates torch_sparse.coalesce's scatter_add over the sorted entries (call site
+ * op_bm_scripts/benchmark_sparse_coalesce.py:35-37).
+ */
+int ora_reduce_runs(const void* value, const int64_t* perm, const int64_t* seg_start, int64_t count, int64_t nnz,
+                    int64_t C, int dtype, void* out) {
+    for (int64_t u = 0; u < count; ++u) {
+        const int64_t beg = seg_start[u], end = (u + 1 < count) ? seg_start[u + 1] : nnz;
+        for (int64_t c = 0; c < C; ++c) {
+            float acc = 0.0f;
+            for (int64_t p = beg; p < end; ++p) acc = acc + ld(value, perm[p] * C + c, dtype);
+            st(out, u * C + c, dtype, acc);
+        }
+    }
+    return 0;
+}

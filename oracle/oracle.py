@@ -187,3 +187,63 @@ def scatter_add_rows_f32(src, index, N):
     out = np.empty((N, src.shape[1]), dtype=np.float32)
     _check(lib().ora_scatter_add_rows_f32(_p(src), _p(index), _p(out), src.shape[0], src.shape[1], N), "scatter_add")
     return out
+
+
+# ---- sparse / sort rows -------------------------------------------------------------------------------
+def spmm(index, value, m, n, matrix, dtype=None):
+    """torch_sparse.spmm(index [2,nnz], value [nnz] or None, m, n, matrix [n,D]) -> [m,D]."""
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    matrix = np.ascontiguousarray(matrix)
+    dt = _dtype_name(matrix, dtype)
+    D = matrix.shape[1]
+    out = np.empty((m, D), dtype=matrix.dtype)
+    val = None if value is None else np.ascontiguousarray(value)
+    row, col = np.ascontiguousarray(index[0]), np.ascontiguousarray(index[1])
+    L = lib()
+    L.ora_spmm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64] * 4 + [ctypes.c_int]
+    _check(L.ora_spmm(_p(row), _p(col), _p(val), _p(matrix), _p(out), index.shape[1], m, n, D, DT[dt]), "spmm")
+    return out
+
+
+def sort(input, dim=-1):
+    """torch.sort(input, dim, stable=True) for float32: ascending, ties by position, NaN last, -0.0 == +0.0
+    (returned as +0.0, the device convention). numpy's stable argsort is the restatement."""
+    x = np.ascontiguousarray(input, dtype=np.float32)
+    idx = np.argsort(x, axis=dim, kind="stable").astype(np.int64)
+    vals = np.take_along_axis(x, idx, axis=dim)
+    vals = np.where(vals == 0, np.float32(0.0), vals)
+    return vals, idx
+
+
+def coalesce(index, value, m, n, dtype=None):
+    """torch_sparse.coalesce(index, value, m, n, op='add'): row-major sorted, duplicates summed in sorted order."""
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    nnz = index.shape[1]
+    key = index[0] * n + index[1]
+    perm = np.argsort(key, kind="stable").astype(np.int64)
+    skey = key[perm]
+    head = np.ones(nnz, dtype=bool)
+    head[1:] = skey[1:] != skey[:-1]
+    seg_start = np.ascontiguousarray(np.nonzero(head)[0].astype(np.int64))
+    ukey = skey[head]
+    out_index = np.stack([ukey // n, ukey % n]).astype(np.int64) if nnz else np.zeros((2, 0), np.int64)
+    if value is None:
+        return out_index, None
+    value = np.ascontiguousarray(value)
+    dt = _dtype_name(value, dtype)
+    C = int(value.size // nnz) if nnz else 0
+    out = np.empty((len(seg_start),) + value.shape[1:], dtype=value.dtype)
+    L = lib()
+    L.ora_reduce_runs.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.c_void_p]
+    _check(L.ora_reduce_runs(_p(value), _p(perm), _p(seg_start), len(seg_start), nnz, C, DT[dt], _p(out)), "coalesce")
+    return out_index, out
+
+
+def transpose_sparse(index, value, m, n, dtype=None):
+    """torch_sparse.transpose(index, value, m, n): swap + coalesce over (n, m)."""
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    return coalesce(np.stack([index[1], index[0]]), value, n, m, dtype=dtype)
+
+
+def transpose_dense(mat):
+    return np.ascontiguousarray(np.ascontiguousarray(mat).T)

@@ -142,9 +142,52 @@ def native_cases():
     return cases
 
 
+def sparse_sort_cases():
+    """torch.sort(stable=True), Tensor.coalesce(), transposed coalesce, torch.sparse.mm on CPU."""
+    cases = {}
+    g = torch.Generator()
+    # sort: tie-heavy inputs as benchmark_native_sort.py:95-97 builds them (dropout p=.9 -> exact zeros)
+    for name, shape in (("1d", (5000,)), ("2d", (37, 53)), ("3d", (6, 11, 9))):
+        g.manual_seed(42)
+        x = torch.rand(shape, generator=g) * 2 - 1
+        x = torch.where(torch.rand(shape, generator=g) < 0.9, torch.zeros(()), x)
+        cases[f"sort_{name}_in"] = x.numpy()
+        for dim in range(len(shape)):
+            v, i = torch.sort(x, stable=True, dim=dim)
+            cases[f"sort_{name}_d{dim}_values"] = v.numpy()
+            cases[f"sort_{name}_d{dim}_indices"] = i.numpy()
+    # coalesce / transpose: duplicated entries as benchmark_sparse_coalesce.py:129-159 builds them
+    g.manual_seed(43)
+    m, n, nnz = 40, 30, 500
+    idx = torch.stack([torch.randint(0, m, (nnz,), generator=g), torch.randint(0, n, (nnz,), generator=g)])
+    idx = torch.cat([idx, idx[:, :200]], dim=1)  # explicit duplicates
+    val = torch.rand(idx.shape[1], generator=g)
+    A = torch.sparse_coo_tensor(idx, val, (m, n))
+    Ac = A.coalesce()
+    At = A.t().coalesce()
+    cases["coo_index"] = idx.numpy()
+    cases["coo_value"] = val.numpy()
+    cases["coo_mn"] = np.array([m, n], dtype=np.int64)
+    cases["coalesce_index"] = Ac.indices().numpy()
+    cases["coalesce_value"] = Ac.values().numpy()
+    cases["transpose_index"] = At.indices().numpy()
+    cases["transpose_value"] = At.values().numpy()
+    # spmm: torch.sparse.mm(COO, dense) (benchmark_sparse_spmm.py:12-14); torch's summation order is its own,
+    # so this vector is checked with a tolerance (1e-5 relative), not bit for bit
+    B = torch.rand(n, 24, generator=g)
+    cases["spmm_B"] = B.numpy()
+    cases["spmm_out"] = torch.sparse.mm(A, B).numpy()
+    # dense transpose copy (benchmark_sparse_transpose.py:13-16), fp16
+    d = torch.rand(45, 70, generator=g).half()
+    cases["dense_in"] = d.numpy()
+    cases["dense_T"] = torch.transpose(d, 0, 1).contiguous().numpy()
+    return cases
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     np.savez_compressed(os.path.join(HERE, "scatter_golden.npz"), **scatter_cases())
     np.savez_compressed(os.path.join(HERE, "native_golden.npz"), **native_cases())
-    for f in ("scatter_golden.npz", "native_golden.npz"):
+    np.savez_compressed(os.path.join(HERE, "sparse_sort_golden.npz"), **sparse_sort_cases())
+    for f in ("scatter_golden.npz", "native_golden.npz", "sparse_sort_golden.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

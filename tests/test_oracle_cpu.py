@@ -137,3 +137,28 @@ def test_oracle_errors():
         oracle.index_select(src, 0, np.array([4]))
     out = oracle.scatter(np.zeros((0, 2), np.float32), np.zeros((0,), np.int64), 0)
     assert out.shape == (0, 2)
+
+
+def test_oracle_sparse_sort_matches_golden():
+    """sort / coalesce / sparse transpose / dense transpose bit-exact vs torch CPU; spmm within 1e-5 (torch's
+    sparse.mm sums in its own order)."""
+    g = load_golden("sparse_sort_golden.npz")
+    for name in ("1d", "2d", "3d"):
+        x = g[f"sort_{name}_in"]
+        for dim in range(x.ndim):
+            v, i = oracle.sort(x, dim)
+            assert_bits_equal(v, g[f"sort_{name}_d{dim}_values"], f"sort {name} d{dim} values")
+            assert_bits_equal(i, g[f"sort_{name}_d{dim}_indices"], f"sort {name} d{dim} indices")
+    m, n = (int(v) for v in g["coo_mn"])
+    ci, cv = oracle.coalesce(g["coo_index"], g["coo_value"], m, n)
+    assert_bits_equal(ci, g["coalesce_index"], "coalesce index")
+    np.testing.assert_allclose(cv, g["coalesce_value"], rtol=1e-6)
+    ti, tv = oracle.transpose_sparse(g["coo_index"], g["coo_value"], m, n)
+    assert_bits_equal(ti, g["transpose_index"], "transpose index")
+    np.testing.assert_allclose(tv, g["transpose_value"], rtol=1e-6)
+    out = oracle.spmm(g["coo_index"], g["coo_value"], m, n, g["spmm_B"])
+    np.testing.assert_allclose(out, g["spmm_out"], rtol=1e-5, atol=1e-6)
+    assert_bits_equal(oracle.transpose_dense(g["dense_in"]), g["dense_T"], "dense transpose")
+    # sort: -0.0 and NaN conventions
+    v, i = oracle.sort(np.array([0.0, -0.0, np.nan, -1.0, 0.0], np.float32), 0)
+    assert list(i) == [3, 0, 1, 4, 2] and np.isnan(v[-1]) and not np.signbit(v[1])

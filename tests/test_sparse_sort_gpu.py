@@ -1,0 +1,135 @@
+"""GPU parity for the sort / sparse rows of SURVEY.md §8(a): a10 sort, a11 spmm, a13 coalesce, a14 transpose.
+Bars: sort values+indices, coalesce/transpose indices and the dense transpose are bit-exact; spmm and the
+coalesced values follow the oracle's sequential fp32 order and are required bit-exact against it (and within
+1e-5 of torch's own CPU result in the golden file)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TORCH_DT, assert_bits_equal, from_np, load_golden, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gnnops():
+    import gnnops as g
+
+    g.load_library()
+    g.set_plan_cache(False)
+    yield g
+    g.set_plan_cache(True)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+def test_golden_sparse_sort(gnnops):
+    g = load_golden("sparse_sort_golden.npz")
+    for name in ("1d", "2d", "3d"):
+        x = torch.from_numpy(g[f"sort_{name}_in"]).cuda()
+        for dim in range(x.dim()):
+            for stable in (True, False):
+                v, i = gnnops.sort(x, dim=dim, stable=stable)
+                assert_bits_equal(v.cpu().numpy(), g[f"sort_{name}_d{dim}_values"], f"sort {name} d{dim} values")
+                assert_bits_equal(i.cpu().numpy(), g[f"sort_{name}_d{dim}_indices"], f"sort {name} d{dim} indices")
+    m, n = (int(v) for v in g["coo_mn"])
+    idx = torch.from_numpy(g["coo_index"]).cuda()
+    val = torch.from_numpy(g["coo_value"]).cuda()
+    import torch_sparse
+
+    ci, cv = torch_sparse.coalesce(idx, val, m, n)
+    assert_bits_equal(ci.cpu().numpy(), g["coalesce_index"], "coalesce index")
+    np.testing.assert_allclose(cv.cpu().numpy(), g["coalesce_value"], rtol=1e-6)
+    ti, tv = torch_sparse.transpose(idx, val, m, n)
+    assert_bits_equal(ti.cpu().numpy(), g["transpose_index"], "transpose index")
+    np.testing.assert_allclose(tv.cpu().numpy(), g["transpose_value"], rtol=1e-6)
+    out = torch_sparse.spmm(idx, val, m, n, torch.from_numpy(g["spmm_B"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), g["spmm_out"], rtol=1e-5, atol=1e-6)
+    dT = gnnops.transpose_contiguous(torch.from_numpy(g["dense_in"]).cuda())
+    assert_bits_equal(dT.cpu().numpy(), g["dense_T"], "dense transpose")
+
+
+@pytest.mark.parametrize("shape,dim", [((100_000,), 0), ((1 << 20,), 0), ((300, 1000), 1), ((300, 1000), 0),
+                                       ((20, 50, 30), 1), ((20, 50, 30), 2), ((8193,), 0), ((1,), 0), ((3, 1), 1)])
+@pytest.mark.parametrize("sparsity", [0.0, 0.9])
+def test_sort_vs_oracle(gnnops, oracle, shape, dim, sparsity):
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(shape, generator=g) * 4 - 2
+    if sparsity:
+        x = torch.nn.functional.dropout(x, p=sparsity)  # exact zeros: massive ties (benchmark_native_sort.py:95-97)
+    v, i = gnnops.sort(x.cuda(), dim=dim, stable=True)
+    ev, ei = oracle.sort(x.numpy(), dim)
+    assert_bits_equal(v.cpu().numpy(), ev, "values")
+    assert_bits_equal(i.cpu().numpy(), ei, "indices")
+
+
+def test_sort_special_values(gnnops, oracle):
+    x = torch.tensor([0.0, -0.0, float("nan"), -1.0, float("inf"), -float("inf"), 0.0, 1e-40, -1e-40])
+    v, i = gnnops.sort(x.cuda(), 0)
+    ev, ei = oracle.sort(x.numpy(), 0)
+    assert_bits_equal(i.cpu().numpy(), ei, "indices")
+    assert torch.isnan(v[-1]) and np.array_equal(v[:-1].cpu().numpy(), ev[:-1])
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("m,n,D,nnz", [(1000, 800, 64, 20000), (300, 300, 256, 6000), (50, 70, 7, 900), (2000, 2000, 1, 30000),
+                                       (64, 64, 320, 500)])
+def test_spmm_bit_exact(gnnops, oracle, m, n, D, nnz, dname):
+    g = torch.Generator().manual_seed(5)
+    idx = torch.stack([torch.randint(0, m, (nnz,), generator=g), torch.randint(0, n, (nnz,), generator=g)])
+    idx[0][idx[0] == 3] = 4  # row 3 empty
+    val = (torch.rand(nnz, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    B = (torch.rand(n, D, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    got = gnnops.spmm(idx.cuda(), val.cuda(), m, n, B.cuda())
+    exp = oracle.spmm(idx.numpy(), to_np(val), m, n, to_np(B), dtype=dname)
+    assert_bits_equal(to_np(got), exp, f"spmm {dname}")
+    if D > 1 and dname == "f32":
+        got1 = gnnops.spmm(idx.cuda(), None, m, n, B.cuda())
+        assert_bits_equal(to_np(got1), oracle.spmm(idx.numpy(), None, m, n, to_np(B), dtype=dname), "spmm value=None")
+        A = torch.sparse_coo_tensor(idx, val, (m, n)).cuda()
+        assert_bits_equal(to_np(gnnops.sparse_mm(A, B.cuda())), exp, "sparse_mm")
+        # CSR entry point (config 3 layout): sorted rows, identity perm
+        order = torch.sort(idx[0], stable=True).indices
+        rowptr = torch.zeros(m + 1, dtype=torch.int64)
+        rowptr[1:] = torch.bincount(idx[0], minlength=m).cumsum(0)
+        got2 = gnnops.spmm_csr(rowptr.cuda(), idx[1][order].cuda(), val[order].cuda(), B.cuda())
+        assert_bits_equal(to_np(got2), exp, "spmm_csr")
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+@pytest.mark.parametrize("m,n,nnz,dup", [(120, 100, 5000, 4), (12000 * 8, 12000 * 8, 40000, 8), (1, 1, 100, 1), (5, 7, 0, 1),
+                                         (3_000_000, 1, 50000, 2)])
+def test_coalesce_and_transpose(gnnops, oracle, m, n, nnz, dup, dname):
+    g = torch.Generator().manual_seed(6)
+    idx = torch.stack([torch.randint(0, m, (nnz,), generator=g), torch.randint(0, n, (nnz,), generator=g)])
+    idx = torch.cat([idx] * dup, dim=1)
+    idx = idx[:, torch.randperm(idx.shape[1], generator=g)]  # benchmark_sparse_coalesce.py:129-159 shuffles the index
+    val = torch.rand(idx.shape[1], generator=g).to(TORCH_DT[dname])
+    ci, cv = gnnops.coalesce(idx.cuda(), val.cuda(), m, n)
+    ei, ev = oracle.coalesce(idx.numpy(), to_np(val), m, n, dtype=dname)
+    assert_bits_equal(ci.cpu().numpy(), ei, "coalesce index")
+    assert_bits_equal(to_np(cv), ev, "coalesce value")
+    ti, tv = gnnops.transpose(idx.cuda(), val.cuda(), m, n)
+    xi, xv = oracle.transpose_sparse(idx.numpy(), to_np(val), m, n, dtype=dname)
+    assert_bits_equal(ti.cpu().numpy(), xi, "transpose index")
+    assert_bits_equal(to_np(tv), xv, "transpose value")
+    ci2, none = gnnops.coalesce(idx.cuda(), None, m, n)
+    assert none is None and np.array_equal(ci2.cpu().numpy(), ei)
+    if dname == "f32" and nnz and m * n < 1 << 40:
+        A = torch.sparse_coo_tensor(idx, val, (m, n)).cuda()
+        Ac = gnnops.coalesce_sparse_tensor(A)
+        assert Ac.is_coalesced() and np.array_equal(Ac.indices().cpu().numpy(), ei)
+
+
+@pytest.mark.parametrize("dname", ["f16", "f32"])
+@pytest.mark.parametrize("R,C", [(2000, 2000), (7071, 333), (65, 129), (1, 500), (64, 64)])
+def test_dense_transpose(gnnops, oracle, R, C, dname):
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(R, C, generator=g).to(TORCH_DT[dname])
+    got = gnnops.transpose_contiguous(x.cuda())
+    assert_bits_equal(to_np(got), oracle.transpose_dense(to_np(x)), "transpose")
