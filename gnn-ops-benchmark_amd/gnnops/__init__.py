@@ -9,6 +9,9 @@ sibling packages ``torch_scatter`` / ``torch_sparse`` in this directory provide 
 from ._lib import GnnopsError, LIB_PATH, load as load_library
 from .ops import (
     Plan,
+    addmm,
+    matmul,
+    index_add_select_sum,
     clear_plan_cache,
     gather,
     get_plan,
@@ -37,5 +40,5 @@ __all__ = [
     "index_add_", "index_max", "index_select", "index_select_sum", "scatter", "scatter_add", "scatter_add_",
     "scatter_max", "scatter_mean", "scatter_min", "scatter_mul", "scatter_reduce_mul_", "scatter_sum",
     "set_plan_cache", "install", "uninstall", "installed", "coalesce", "coalesce_sparse_tensor", "sort", "sparse_mm",
-    "spmm", "spmm_csr", "transpose", "transpose_contiguous",
+    "spmm", "spmm_csr", "transpose", "transpose_contiguous", "addmm", "matmul", "index_add_select_sum",
 ]

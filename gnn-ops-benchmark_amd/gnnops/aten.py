@@ -3,7 +3,8 @@
 Reference call sites: torch.index_select (op_bm_scripts/benchmark_native_index_select.py:14),
 Tensor.index_add_ (benchmark_native_index_add_.py:15), torch.gather (benchmark_native_gather.py:16),
 Tensor.scatter_add_ (benchmark_scatter_add.py:24), torch.index_add
-(benchmark_fused_index_add_reduce.py:13).
+(benchmark_fused_index_add_reduce.py:13), torch.sort (benchmark_native_sort.py:29), torch.addmm / torch.matmul
+(benchmark_native_addmm.py:15, benchmark_native_matmul.py:15).
 
 ROCm builds of PyTorch register device kernels under the "CUDA" dispatch key, so overriding that key is
 what makes ``device="cuda"`` script text reach our kernels. ``install()`` is reversible: ``uninstall()``
@@ -45,6 +46,26 @@ def install():
     def scatter_add(self, dim, index, src):
         return ops.scatter_add_(self.clone(), dim, index, src)
 
+    def sort_stable(self, *, stable, dim=-1, descending=False):
+        from . import sparse
+
+        return sparse.sort(self, dim=dim, descending=descending, stable=bool(stable))
+
+    def sort_default(self, dim=-1, descending=False):
+        from . import sparse
+
+        return sparse.sort(self, dim=dim, descending=descending)
+
+    def addmm(self, mat1, mat2, *, beta=1, alpha=1):
+        return ops.addmm(self, mat1, mat2, beta=beta, alpha=alpha)
+
+    def mm(self, mat2):
+        return ops.matmul(self, mat2)
+
+    lib.impl("sort.stable", sort_stable, "CUDA")
+    lib.impl("sort", sort_default, "CUDA")
+    lib.impl("addmm", addmm, "CUDA")
+    lib.impl("mm", mm, "CUDA")
     lib.impl("index_select", index_select, "CUDA")
     lib.impl("gather", gather, "CUDA")
     lib.impl("index_add_", index_add_, "CUDA")

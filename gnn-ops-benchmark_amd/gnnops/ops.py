@@ -417,3 +417,71 @@ def index_select_sum(input, dim, index):
                                              index.numel(), dt, ws.data_ptr(), ws_bytes, _stream())
     check(rc, "fused_index_select_sum")
     return out
+
+
+def index_add_select_sum(input, dim, index, other):
+    """fp32 value of ``torch.index_select(torch.index_add(input, dim, index, other), dim, index).sum(dim)``
+    (benchmark_fused_index_add_reduce.py:12-20) in one pass; nothing of input's size is materialised."""
+    is_plan = isinstance(index, Plan)
+    _require_gpu(input, other, None if is_plan else index)
+    dt = _dtype_code(input, "index_add_select_sum")
+    if other.dtype != input.dtype:
+        raise RuntimeError("index_add_select_sum: input and other must have the same dtype")
+    dim = _norm_dim(dim, input.dim(), "index_add_select_sum")
+    input = input.contiguous()
+    other = other.contiguous()
+    B, N, K = _bek(input.shape, dim)
+    Bo, E, Ko = _bek(other.shape, dim)
+    if (Bo, Ko) != (B, K):
+        raise RuntimeError("index_add_select_sum: other must match input outside `dim`")
+    if not is_plan:
+        _check_index(index, "index_add_select_sum")
+        if index.numel() != E:
+            raise IndexError("index_add_select_sum: index length must equal other.size(dim)")
+    plan = get_plan(index if is_plan else index.contiguous().view(-1), N)
+    shape = list(input.shape)
+    del shape[dim]
+    out = torch.empty(shape, dtype=torch.float32, device=input.device)
+    L = _lib.load()
+    ws_bytes = L.gnnops_fused_index_add_select_sum_workspace_bytes(B, K)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = L.gnnops_fused_index_add_select_sum(input.data_ptr(), other.data_ptr(), plan.rowptr.data_ptr(),
+                                                 plan.perm.data_ptr(), out.data_ptr(), B, N, E, K, dt, ws.data_ptr(),
+                                                 ws_bytes, _stream())
+    check(rc, "fused_index_add_select_sum")
+    return out
+
+
+def addmm(input, mat1, mat2, *, beta=1, alpha=1):
+    """torch.addmm(input, mat1, mat2) for float16 / bfloat16 matrices (benchmark_native_addmm.py:13-16)."""
+    if beta != 1 or alpha != 1:
+        raise NotImplementedError("gnnops.addmm: beta and alpha must be 1")
+    _require_gpu(input, mat1, mat2)
+    if mat1.dim() != 2 or mat2.dim() != 2:
+        raise RuntimeError("addmm: mat1 and mat2 must be matrices")
+    if mat1.size(1) != mat2.size(0):
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({mat1.size(0)}x{mat1.size(1)} and "
+                           f"{mat2.size(0)}x{mat2.size(1)})")
+    if mat1.dtype != mat2.dtype or (input is not None and input.dtype != mat1.dtype):
+        raise RuntimeError("addmm: operands must have the same dtype")
+    if mat1.dtype not in (torch.float16, torch.bfloat16):
+        raise NotImplementedError(f"gnnops.addmm: dtype {mat1.dtype} is not supported (float16/bfloat16)")
+    dt = _DT[mat1.dtype]
+    M, K = mat1.shape
+    N = mat2.size(1)
+    if input is not None:
+        input = input.expand(M, N).contiguous()
+    mat1 = mat1.contiguous()
+    mat2 = mat2.contiguous()
+    out = torch.empty((M, N), dtype=mat1.dtype, device=mat1.device)
+    with torch.cuda.device(mat1.device):
+        rc = _lib.load().gnnops_addmm(input.data_ptr() if input is not None else None, mat1.data_ptr(), mat2.data_ptr(),
+                                      out.data_ptr(), M, N, K, dt, _stream())
+    check(rc, "addmm")
+    return out
+
+
+def matmul(input, other):
+    """torch.matmul(input, other) for 2-D float16 / bfloat16 matrices (benchmark_native_matmul.py:13-16)."""
+    return addmm(None, input, other)

@@ -180,6 +180,26 @@ int gnnops_coalesce(const int64_t* row, const int64_t* col, const void* value, i
 int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes,
                        gnnops_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * torch.addmm(input, mat1, mat2) / torch.matmul(input, other) on 16-bit operands
+ * (benchmark_native_addmm.py:13-16, benchmark_native_matmul.py:13-16): out[M,N] = input[M,N] + mat1[M,K] @
+ * mat2[K,N] (input == NULL: plain matmul). Row-major, dtype F16 or BF16, fp32 MFMA accumulation, one rounding.
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out,
+                 int64_t M, int64_t N, int64_t K, int dtype, gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused index_select(index_add(input, dim, index, other), dim, index).sum(dim)
+ * (benchmark_fused_index_add_reduce.py:12-20). input [B,N,K], other [B,E,K], plan of index over N.
+ * out_f32 [B,K] (fp32: the reference's fp16 result overflows at its own sizes). Nothing of size [B,N,K]
+ * is materialised. workspace only when K > 1.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnnops_fused_index_add_select_sum_workspace_bytes(int64_t B, int64_t K);
+int gnnops_fused_index_add_select_sum(const void* input, const void* other,
+                                      const int32_t* rowptr, const int32_t* perm, float* out_f32,
+                                      int64_t B, int64_t N, int64_t E, int64_t K, int dtype,
+                                      void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

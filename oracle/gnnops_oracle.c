@@ -280,3 +280,44 @@ int ora_reduce_runs(const void* value, const int64_t* perm, const int64_t* seg_s
     }
     return 0;
 }
+
+/* addmm / matmul (benchmark_native_addmm.py:13-16): out = input + A[M,K] @ B[K,N], double accumulation
+ * (the device sums inside the MFMA in fp32; compared with a tolerance that scales with sqrt(K)). */
+int ora_addmm(const void* input, const void* A, const void* B, double* out, int64_t M, int64_t N, int64_t K, int dtype) {
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t j = 0; j < N; ++j) out[i * N + j] = input ? (double)ld(input, i * N + j, dtype) : 0.0;
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t k = 0; k < K; ++k) {
+            const double a = (double)ld(A, i * K + k, dtype);
+            for (int64_t j = 0; j < N; ++j) out[i * N + j] += a * (double)ld(B, k * N + j, dtype);
+        }
+    return 0;
+}
+
+/* index_select(index_add(input, dim, index, other), dim, index).sum(dim)
+ * (benchmark_fused_index_add_reduce.py:12-20) restated literally on [B,N,K] / [B,E,K]: tmp = input with
+ * other accumulated in fp32 per destination in order and rounded once to the storage type (the
+ * index_add convention of this oracle), then a double sum over the selected rows. */
+int ora_index_add_select_sum(const void* input, const void* other, const int64_t* index, double* out, int64_t B,
+                             int64_t N, int64_t E, int64_t K, int dtype) {
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)(B * N * K > 0 ? B * N * K : 1));
+    if (!tmp) return 2;
+    for (int64_t i = 0; i < B * N * K; ++i) tmp[i] = ld(input, i, dtype);
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t e = 0; e < E; ++e) {
+            if (index[e] < 0 || index[e] >= N) { free(tmp); return 1; }
+            for (int64_t k = 0; k < K; ++k) tmp[(b * N + index[e]) * K + k] += ld(other, (b * E + e) * K + k, dtype);
+        }
+    if (dtype != ORA_F32) { /* one rounding to the storage type */
+        uint16_t h;
+        for (int64_t i = 0; i < B * N * K; ++i) { st(&h, 0, dtype, tmp[i]); tmp[i] = ld(&h, 0, dtype); }
+    }
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t k = 0; k < K; ++k) {
+            double s = 0.0;
+            for (int64_t e = 0; e < E; ++e) s += (double)tmp[(b * N + index[e]) * K + k];
+            out[b * K + k] = s;
+        }
+    free(tmp);
+    return 0;
+}

@@ -247,3 +247,33 @@ def transpose_sparse(index, value, m, n, dtype=None):
 
 def transpose_dense(mat):
     return np.ascontiguousarray(np.ascontiguousarray(mat).T)
+
+
+def addmm(input, mat1, mat2, dtype=None):
+    """float64 reference of torch.addmm(input, mat1, mat2) on the (rounded) 16-bit operands; input may be None."""
+    mat1, mat2 = np.ascontiguousarray(mat1), np.ascontiguousarray(mat2)
+    dt = _dtype_name(mat1, dtype)
+    M, K = mat1.shape
+    N = mat2.shape[1]
+    out = np.empty((M, N), dtype=np.float64)
+    inp = None if input is None else np.ascontiguousarray(input)
+    L = lib()
+    L.ora_addmm.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 3 + [ctypes.c_int]
+    _check(L.ora_addmm(_p(inp), _p(mat1), _p(mat2), _p(out), M, N, K, DT[dt]), "addmm")
+    return out
+
+
+def index_add_select_sum(input, dim, index, other, dtype=None):
+    """float64 value of index_select(index_add(input, dim, index, other), dim, index).sum(dim)."""
+    input, other = np.ascontiguousarray(input), np.ascontiguousarray(other)
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    dt = _dtype_name(input, dtype)
+    B, N, K, dim = _bek(input.shape, dim)
+    E = other.shape[dim]
+    shape = list(input.shape)
+    del shape[dim]
+    out = np.empty(shape, dtype=np.float64)
+    L = lib()
+    L.ora_index_add_select_sum.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 4 + [ctypes.c_int]
+    _check(L.ora_index_add_select_sum(_p(input), _p(other), _p(index), _p(out), B, N, E, K, DT[dt]), "index_add_select_sum")
+    return out

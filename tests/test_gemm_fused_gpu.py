@@ -1,0 +1,106 @@
+"""GPU parity: a17 addmm / matmul (MFMA GEMM) and a16 fused index_add + index_select + sum.
+
+addmm tolerance (stated, north_star "stated fp tolerance"): the device accumulates K products in fp32 inside the
+MFMA and rounds once to the 16-bit output, so |got - exact| <= 2^-8 (bf16) / 2^-11 (fp16) relative rounding of
+the result plus fp32 accumulation error ~ K * 2^-24 * sum|a*b|. Checked as
+    |got - ref64| <= eps_out * |ref64| + 4 * K * 2^-24 * (|A| @ |B|).
+fused: fp32 partial sums vs a double reference, relative 1e-5 of the sum of magnitudes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TORCH_DT, f32_of, to_np
+
+pytestmark = pytest.mark.gpu
+EPS_OUT = {"f16": 2.0 ** -11, "bf16": 2.0 ** -8}
+
+
+@pytest.fixture(scope="module")
+def gnnops():
+    import gnnops as g
+
+    g.load_library()
+    return g
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+@pytest.mark.parametrize("dname", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 512), (130, 70, 100), (1, 1, 1), (17, 9, 40), (333, 257, 191),
+                                   (64, 64, 8), (512, 256, 1024)])
+def test_addmm_matmul(gnnops, oracle, M, N, K, dname):
+    g = torch.Generator().manual_seed(3)
+    # asymmetric operands (row/col swaps in the C write would show)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    B = (torch.rand(K, N, generator=g) * 2 - 1 + torch.arange(N).float().view(1, N) / max(N, 1)).to(TORCH_DT[dname])
+    C = (torch.rand(M, N, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    bound_acc = 4 * K * 2.0 ** -24 * (A.double().abs() @ B.double().abs()).numpy()
+    for inp in (C, None):
+        got = gnnops.addmm(inp.cuda(), A.cuda(), B.cuda()) if inp is not None else gnnops.matmul(A.cuda(), B.cuda())
+        ref = oracle.addmm(None if inp is None else to_np(inp), to_np(A), to_np(B), dtype=dname)
+        err = np.abs(f32_of(to_np(got), dname).astype(np.float64) - ref)
+        bound = EPS_OUT[dname] * np.abs(ref) + bound_acc + 1e-30
+        assert (err <= bound).all(), f"max err/bound {np.max(err / bound)} at {np.unravel_index(np.argmax(err / bound), err.shape)}"
+
+
+def test_addmm_identity_layout(gnnops):
+    """A = I with an asymmetric B: catches fragment-layout and transposed-read mistakes exactly."""
+    n = 192
+    B = (torch.arange(n * n).view(n, n) % 251).to(torch.bfloat16)  # integers < 256 are exact in bf16
+    I = torch.eye(n, dtype=torch.bfloat16)
+    assert torch.equal(gnnops.matmul(I.cuda(), B.cuda()).cpu(), B)
+    assert torch.equal(gnnops.matmul(B.cuda(), I.cuda()).cpu(), B)
+
+
+def test_addmm_reference_shape_fp16(gnnops):
+    """The reference's first sweep length (benchmark_native_addmm.py:23-38: L = 1581, fp16): odd, unaligned rows."""
+    L = 1581
+    g = torch.Generator().manual_seed(4)
+    A = torch.rand(L, L, generator=g).half()
+    B = torch.rand(L, L, generator=g).half()
+    C = torch.rand(L, L, generator=g).half()
+    got = gnnops.addmm(C.cuda(), A.cuda(), B.cuda()).float().cpu()
+    ref = (C.double() + A.double() @ B.double())
+    rel = ((got.double() - ref).abs() / ref.abs()).max().item()
+    assert rel <= 2.0 ** -10, rel
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("L", [300, 1000])
+def test_fused_index_add_select_sum(gnnops, oracle, L, dname):
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(L, L, generator=g).to(TORCH_DT[dname])
+    for dim in (0, 1):
+        idx = torch.randint(0, L, (L,), generator=g)
+        got = gnnops.index_add_select_sum(x.cuda(), dim, idx.cuda(), x.clone().cuda()).cpu().numpy().astype(np.float64)
+        ref = oracle.index_add_select_sum(to_np(x), dim, idx.numpy(), to_np(x), dtype=dname)
+        assert got.shape == ref.shape == (L,)
+        assert np.max(np.abs(got - ref) / np.abs(ref).max()) <= 1e-5
+
+
+def test_aten_sort_and_addmm_overrides(gnnops):
+    g = torch.Generator().manual_seed(23)
+    x = torch.nn.functional.dropout(torch.rand(200, 300, generator=g), p=0.9)
+    A = torch.rand(96, 64, generator=g).half()
+    B = torch.rand(64, 80, generator=g).half()
+    C = torch.rand(96, 80, generator=g).half()
+    ev, ei = torch.sort(x, dim=1, stable=True)
+    gnnops.install()
+    try:
+        v, i = torch.sort(x.cuda(), dim=1, stable=True)
+        v2, i2 = torch.sort(x.cuda(), 0)
+        out = torch.addmm(C.cuda(), A.cuda(), B.cuda())
+        mm = torch.matmul(A.cuda(), B.cuda())
+    finally:
+        gnnops.uninstall()
+    assert torch.equal(v.cpu(), ev) and torch.equal(i.cpu(), ei)
+    assert torch.equal(v2.cpu(), torch.sort(x, dim=0, stable=True).values)
+    ref = C.double() + A.double() @ B.double()
+    assert ((out.double().cpu() - ref).abs() / ref.abs()).max() <= 2.0 ** -10
+    assert ((mm.double().cpu() - A.double() @ B.double()).abs().max()) <= 2.0 ** -10 * 64
