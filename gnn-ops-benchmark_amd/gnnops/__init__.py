@@ -31,7 +31,7 @@ from .ops import (
     scatter_sum,
     set_plan_cache,
 )
-from .sparse import (coalesce, coalesce_sparse_tensor, sort, sparse_mm, spmm, spmm_csr, transpose,
+from .sparse import (coalesce, coalesce_sparse_tensor, sort, sparse_mm, spmm, spmm_csr, spspmm, transpose,
                      transpose_contiguous)
 from .aten import install, uninstall, installed
 
@@ -40,5 +40,5 @@ __all__ = [
     "index_add_", "index_max", "index_select", "index_select_sum", "scatter", "scatter_add", "scatter_add_",
     "scatter_max", "scatter_mean", "scatter_min", "scatter_mul", "scatter_reduce_mul_", "scatter_sum",
     "set_plan_cache", "install", "uninstall", "installed", "coalesce", "coalesce_sparse_tensor", "sort", "sparse_mm",
-    "spmm", "spmm_csr", "transpose", "transpose_contiguous", "addmm", "matmul", "index_add_select_sum",
+    "spmm", "spmm_csr", "spspmm", "transpose", "transpose_contiguous", "addmm", "matmul", "index_add_select_sum",
 ]

@@ -61,13 +61,47 @@ def _spmm_launch(rowptr, perm, col, value, matrix, m, dt):
 
 
 def sparse_mm(mat_a, mat_b):
-    """torch.sparse.mm(sparse COO [m,n], dense [n,D]) -> dense [m,D] (benchmark_sparse_spmm.py:12-14)."""
+    """torch.sparse.mm: sparse COO [m,n] x dense [n,D] -> dense (benchmark_sparse_spmm.py:12-14);
+    sparse x sparse -> coalesced sparse COO (benchmark_sparse_spspmm.py:12-14)."""
     if not mat_a.is_sparse:
         raise RuntimeError("sparse_mm: first operand must be a sparse COO tensor")
-    if mat_b.is_sparse:
-        raise NotImplementedError("gnnops.sparse_mm: sparse x sparse goes through spspmm")
     m, n = mat_a.shape
+    if mat_b.is_sparse:
+        idx, val = spspmm(mat_a._indices(), mat_a._values(), mat_b._indices(), mat_b._values(), m, n, mat_b.size(1))
+        return torch.sparse_coo_tensor(idx, val, (m, mat_b.size(1)))._coalesced_(True)
     return spmm(mat_a._indices(), mat_a._values(), m, n, mat_b)
+
+
+def spspmm(indexA, valueA, indexB, valueB, m, k, n, coalesced=False):
+    """torch_sparse.spspmm(indexA, valueA, indexB, valueB, m, k, n): (m x k) @ (k x n), coalesced COO result.
+    Two host round trips size the expansion and the result (the upstream op synchronises for the same reason)."""
+    _require_gpu(indexA, valueA, indexB, valueB)
+    indexA, rowA, colA = _coo_rows_cols(indexA, "spspmm")
+    indexB, rowB, colB = _coo_rows_cols(indexB, "spspmm")
+    dt = _dtype_code(valueA, "spspmm")
+    if valueB.dtype != valueA.dtype:
+        raise RuntimeError("spspmm: valueA and valueB must have the same dtype")
+    valueA, valueB = valueA.contiguous(), valueB.contiguous()
+    nnzA = indexA.size(1)
+    dev = indexA.device
+    L = _lib.load()
+    planB = get_plan(rowB, k)
+    ws_bytes = L.gnnops_spspmm_workspace_bytes(nnzA)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(L.gnnops_spspmm_count(colA.data_ptr(), nnzA, planB.rowptr.data_ptr(), total.data_ptr(), ws.data_ptr(),
+                                    ws_bytes, _stream()), "spspmm_count")
+        P = int(total.item())
+        if P >= 1 << 32:
+            raise NotImplementedError(f"gnnops.spspmm: {P} partial products exceed the 2^32 limit")
+        ex_index = torch.empty((2, P), dtype=torch.int64, device=dev)
+        ex_value = torch.empty(P, dtype=valueA.dtype, device=dev)
+        check(L.gnnops_spspmm_expand(rowA.data_ptr(), colA.data_ptr(), valueA.data_ptr(), nnzA, planB.rowptr.data_ptr(),
+                                     planB.perm.data_ptr(), colB.data_ptr(), valueB.data_ptr(), ex_index[0].data_ptr(),
+                                     ex_index[1].data_ptr(), ex_value.data_ptr(), dt, ws.data_ptr(), _stream()),
+              "spspmm_expand")
+    return coalesce(ex_index, ex_value, m, n)
 
 
 def coalesce(index, value, m, n, op="add"):

@@ -200,6 +200,21 @@ int gnnops_fused_index_add_select_sum(const void* input, const void* other,
                                       int64_t B, int64_t N, int64_t E, int64_t K, int dtype,
                                       void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * torch_sparse.spspmm / torch.sparse.mm(COO, COO) (benchmark_sparse_spspmm.py:12-14,94-95):
+ * C = A(m x k) @ B(k x n) by expand - sort - compress. B is given as the plan (rowptrB, permB) of its row
+ * index plus colB/valB. Phase 1 counts the products (*d_total, device int64) so the caller can size the
+ * expansion; phase 2 writes them in (nonzero of A, nonzero of B's row) order; gnnops_coalesce over
+ * (out_row, out_col, out_val, m, n) then yields the coalesced result. `workspace` is shared by both phases.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnnops_spspmm_workspace_bytes(int64_t nnzA);
+int gnnops_spspmm_count(const int64_t* colA, int64_t nnzA, const int32_t* rowptrB, int64_t* d_total,
+                        void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+int gnnops_spspmm_expand(const int64_t* rowA, const int64_t* colA, const void* valA, int64_t nnzA,
+                         const int32_t* rowptrB, const int32_t* permB, const int64_t* colB, const void* valB,
+                         int64_t* out_row, int64_t* out_col, void* out_val, int dtype,
+                         const void* workspace, gnnops_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,3 +277,46 @@ def index_add_select_sum(input, dim, index, other, dtype=None):
     L.ora_index_add_select_sum.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 4 + [ctypes.c_int]
     _check(L.ora_index_add_select_sum(_p(input), _p(other), _p(index), _p(out), B, N, E, K, DT[dt]), "index_add_select_sum")
     return out
+
+
+def spspmm(indexA, valueA, indexB, valueB, m, k, n, dtype=None):
+    """torch_sparse.spspmm restated as expand - sort - compress: products enumerated over A's entries in order
+    and, for each, over B's row in stored order; product rounded to the storage type; duplicates summed in that
+    order by `coalesce` (reference call site: op_bm_scripts/benchmark_sparse_spspmm.py:12-14)."""
+    indexA = np.ascontiguousarray(indexA, dtype=np.int64)
+    indexB = np.ascontiguousarray(indexB, dtype=np.int64)
+    valueA, valueB = np.ascontiguousarray(valueA), np.ascontiguousarray(valueB)
+    dt = _dtype_name(valueA, dtype)
+    rowptr, perm = plan(indexB[0], k)
+    a32 = _widen(valueA, dt)
+    b32 = _widen(valueB, dt)
+    rows, cols, vals = [], [], []
+    for a in range(indexA.shape[1]):
+        kk = indexA[1, a]
+        es = perm[rowptr[kk]:rowptr[kk + 1]]
+        rows.append(np.full(len(es), indexA[0, a], dtype=np.int64))
+        cols.append(indexB[1, es])
+        vals.append((a32[a] * b32[es]).astype(np.float32))
+    if rows:
+        ex_index = np.stack([np.concatenate(rows), np.concatenate(cols)])
+        ex_val = _narrow(np.concatenate(vals), dt)
+    else:
+        ex_index = np.zeros((2, 0), np.int64)
+        ex_val = _narrow(np.zeros(0, np.float32), dt)
+    return coalesce(ex_index, ex_val, m, n, dtype=dt)
+
+
+def _widen(a, dt):
+    if dt == "bf16":
+        return (a.astype(np.uint32) << 16).view(np.float32)
+    return a.astype(np.float32)
+
+
+def _narrow(a32, dt):
+    """fp32 -> storage type with round-to-nearest-even (through the C conversions for bf16)."""
+    if dt == "f32":
+        return a32.astype(np.float32)
+    if dt == "f16":
+        return a32.astype(np.float16)
+    L = lib()
+    return np.array([L.ora_f32_to_bf16(float(v)) for v in a32], dtype=np.uint16)

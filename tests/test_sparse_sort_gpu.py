@@ -133,3 +133,28 @@ def test_dense_transpose(gnnops, oracle, R, C, dname):
     x = torch.rand(R, C, generator=g).to(TORCH_DT[dname])
     got = gnnops.transpose_contiguous(x.cuda())
     assert_bits_equal(to_np(got), oracle.transpose_dense(to_np(x)), "transpose")
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+@pytest.mark.parametrize("m,k,n,nnzA,nnzB", [(60, 50, 70, 400, 500), (1414, 1414, 1414, 10000, 10000), (5, 4, 3, 0, 7),
+                                             (8, 300, 9, 50, 2000)])
+def test_spspmm(gnnops, oracle, m, k, n, nnzA, nnzB, dname):
+    """sparsity .995 at L=1414 is the reference's first sweep point (benchmark_sparse_spspmm.py:28-30)."""
+    g = torch.Generator().manual_seed(31)
+    ia = torch.stack([torch.randint(0, m, (nnzA,), generator=g), torch.randint(0, k, (nnzA,), generator=g)])
+    ib = torch.stack([torch.randint(0, k, (nnzB,), generator=g), torch.randint(0, n, (nnzB,), generator=g)])
+    va = (torch.rand(nnzA, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    vb = (torch.rand(nnzB, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    import torch_sparse
+
+    gi, gv = torch_sparse.spspmm(ia.cuda(), va.cuda(), ib.cuda(), vb.cuda(), m, k, n)
+    ei, ev = oracle.spspmm(ia.numpy(), to_np(va), ib.numpy(), to_np(vb), m, k, n, dtype=dname)
+    assert_bits_equal(gi.cpu().numpy(), ei, "spspmm index")
+    assert_bits_equal(to_np(gv), ev, "spspmm value")
+    if dname == "f32" and nnzA:
+        A = torch.sparse_coo_tensor(ia, va, (m, k)).coalesce()
+        Bs = torch.sparse_coo_tensor(ib, vb, (k, n)).coalesce()
+        ref = torch.sparse.mm(A, Bs).coalesce()  # torch's own CPU SpGEMM: same pattern, values within fp32 tolerance
+        got = gnnops.sparse_mm(A.cuda(), Bs.cuda())
+        assert got.is_coalesced() and np.array_equal(got.indices().cpu().numpy(), ref.indices().numpy())
+        np.testing.assert_allclose(got.values().cpu().numpy(), ref.values().numpy(), rtol=1e-4, atol=1e-6)
