@@ -13,8 +13,9 @@
 //   4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles (64 accumulator VGPRs); next tile's global loads
 //     are issued before the MFMA block of the current one.
 // First version: single LDS buffer, two barriers per K-step (the guide's "step-3" structure, ~1/3 of
-// the MFMA roof); the deeper 256^2 pipeline is the follow-up. Odd sizes (L = 1581) take guarded
-// element loads for the edge/unaligned rows.
+// the MFMA roof); the deeper 256^2 pipeline is the follow-up. Operands whose row length is not a multiple of
+// 8 elements (the reference sweeps L = 1581 ... 8164) are first copied into 16-B aligned, zero-padded rows
+// (pad_rows_kernel, workspace), so the staging loads are always 16-B vectors.
 #include "common.h"
 
 namespace {
@@ -44,7 +45,7 @@ __device__ inline u32x4 load8(const uint16_t* __restrict__ base, int64_t r, int6
     u32x4 v = {0u, 0u, 0u, 0u};
     if (r >= rows || c >= cols) return v;
     const uint16_t* p = base + r * ld + c;
-    if (vec_ok && c + 8 <= cols) return *reinterpret_cast<const u32x4*>(p);
+    if (vec_ok && c + 8 <= ld) return *reinterpret_cast<const u32x4*>(p);  // ld % 8 == 0; padded tail is zero
     uint16_t e[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = (c + i < cols) ? p[i] : (uint16_t)0;
@@ -56,7 +57,8 @@ __device__ inline u32x4 load8(const uint16_t* __restrict__ base, int64_t r, int6
 template <typename T, bool IS_BF16>
 __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
                                                    const T* __restrict__ addend, T* __restrict__ C, int64_t M,
-                                                   int64_t N, int64_t K, bool a_vec, bool b_vec) {
+                                                   int64_t N, int64_t K, int64_t lda, int64_t ldb, bool a_vec,
+                                                   bool b_vec) {
     __shared__ __attribute__((aligned(16))) uint16_t sA[BM * AS];
     __shared__ __attribute__((aligned(16))) uint16_t sB[BK * BS];
 
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
     auto gload = [&](int64_t k0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            ra[p] = load8(A, m0 + a_row[p], k0 + a_chk * 8, M, K, K, a_vec);
-            rb[p] = load8(Bm, k0 + b_row[p], n0 + b_chk * 8, K, N, N, b_vec);
+            ra[p] = load8(A, m0 + a_row[p], k0 + a_chk * 8, M, K, lda, a_vec);
+            rb[p] = load8(Bm, k0 + b_row[p], n0 + b_chk * 8, K, N, ldb, b_vec);
         }
     };
 
@@ -134,10 +136,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
             }
 }
 
+// Copy a [rows][cols] 16-bit matrix into rows of `ld` elements (ld % 8 == 0), zero-filling the tail, so that every
+// row starts 16-B aligned and the GEMM's 16-B staging loads apply (the reference sweeps odd sizes: L = 1581...).
+__global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t cols,
+                                int64_t ld) {
+    const int64_t chunks = ld / 8, total = rows * chunks;  // one 16-B output chunk per thread
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks, c = (i % chunks) * 8;
+        const uint16_t* p = in + r * cols + c;
+        uint16_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (c + j < cols) ? p[j] : (uint16_t)0;
+        u32x4 v;
+        v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+        v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+        *reinterpret_cast<u32x4*>(out + r * ld + c) = v;
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int64_t round8(int64_t v) { return (v + 7) / 8 * 8; }
+
 }  // namespace
 
+extern "C" size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M < 0 || N < 0 || K < 0) return 0;
+    size_t b = 0;
+    if (K % 8) b += align_up((size_t)M * round8(K) * 2, 256);
+    if (N % 8) b += align_up((size_t)K * round8(N) * 2, 256);
+    return b;
+}
+
 extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N,
-                            int64_t K, int dtype, gnnops_stream_t s) {
+                            int64_t K, int dtype, void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(M >= 0 && N >= 0 && K >= 0, GNNOPS_EINVAL, "addmm: negative size");
     GNNOPS_REQUIRE(dtype == GNNOPS_F16 || dtype == GNNOPS_BF16, GNNOPS_EUNSUPPORTED,
@@ -145,14 +176,32 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
     if (M * N == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(out && (K == 0 || (mat1 && mat2)), GNNOPS_EINVAL, "addmm: null pointer");
     GNNOPS_REQUIRE(gnnops_cdiv(M, BM) < 65536, GNNOPS_EUNSUPPORTED, "addmm: M too large for the grid");
-    const bool a_vec = (K % 8 == 0) && ((uintptr_t)mat1 % 16 == 0);
-    const bool b_vec = (N % 8 == 0) && ((uintptr_t)mat2 % 16 == 0);
+    const size_t need = gnnops_addmm_workspace_bytes(M, N, K);
+    GNNOPS_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), GNNOPS_EWORKSPACE, "addmm: workspace %zu < %zu",
+                   workspace_bytes, need);
+    int64_t lda = K, ldb = N;
+    char* w = (char*)workspace;
+    if (K % 8 && K > 0) {
+        lda = round8(K);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(gnnops_grid_cap(gnnops_cdiv(M * lda / 8, 256), 256 * 16)), dim3(256), 0, stream,
+                           (const uint16_t*)mat1, (uint16_t*)w, M, K, lda);
+        mat1 = w;
+        w += align_up((size_t)M * lda * 2, 256);
+    }
+    if (N % 8 && K > 0) {
+        ldb = round8(N);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(gnnops_grid_cap(gnnops_cdiv(K * ldb / 8, 256), 256 * 16)), dim3(256), 0, stream,
+                           (const uint16_t*)mat2, (uint16_t*)w, K, N, ldb);
+        mat2 = w;
+    }
+    const bool a_vec = (uintptr_t)mat1 % 16 == 0;
+    const bool b_vec = (uintptr_t)mat2 % 16 == 0;
     dim3 grid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
     if (dtype == GNNOPS_BF16)
         hipLaunchKernelGGL((gemm_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                           (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, a_vec, b_vec);
+                           (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb, a_vec, b_vec);
     else
         hipLaunchKernelGGL((gemm_kernel<__half, false>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                           (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, a_vec, b_vec);
+                           (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb, a_vec, b_vec);
     return gnnops_check_launch("addmm");
 }

@@ -144,6 +144,127 @@ __global__ void zero_empty_kernel(T* __restrict__ out, const int64_t* __restrict
     GRID_STRIDE(i, n) if (arg_out[i] == E) Elem<T>::store(out + i, 0.f);
 }
 
+// ---- LDS-privatised form ---------------------------------------------------------------------------------
+// When all destinations of one (b, column strip) fit in LDS — N * TC accumulators — a workgroup owns the
+// strip: it streams its part of src / index once (coalesced along the strip), combines into LDS with LDS
+// atomics (two orders of magnitude cheaper than memory-side atomics, MI355X_MICROARCH.md "Global float
+// atomics"), and writes each output element exactly once. The reference's own shapes ((L, L) fp16, index of
+// the full shape, dim 0 or 1, L <= 6708) all take this path: HBM-bound on the 8-B index.
+constexpr int LDS_THREADS = 1024;
+constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
+
+template <typename T, int R>
+__global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __restrict__ src,
+                                                                  const int64_t* __restrict__ index,
+                                                                  T* __restrict__ out, int64_t* __restrict__ arg_out,
+                                                                  int64_t B, int64_t E, int64_t K, int64_t N, int TC,
+                                                                  int strips, int init_from_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float* acc = reinterpret_cast<float*>(lds_raw);
+    int* aux = reinterpret_cast<int*>(lds_raw) + (size_t)N * TC;  // counts (MEAN) or arg (MIN/MAX)
+    constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
+    const int64_t b = blockIdx.x / strips;
+    const int64_t k0 = (int64_t)(blockIdx.x % strips) * TC;
+    const int tc = (int)((K - k0 < TC) ? (K - k0) : TC);
+    const int64_t nacc = N * tc;
+    const float ident = (R == GNNOPS_MUL) ? 1.f : (R == GNNOPS_MIN) ? __builtin_huge_valf()
+                        : (R == GNNOPS_MAX) ? -__builtin_huge_valf() : 0.f;
+
+    for (int64_t i = threadIdx.x; i < nacc; i += LDS_THREADS) {
+        const int64_t n = i / tc, kk = i % tc;
+        acc[i] = init_from_out ? Elem<T>::load(out + (b * N + n) * K + k0 + kk) : ident;
+        if (R == GNNOPS_MEAN) aux[i] = 0;
+        if (IS_ARG) aux[i] = (int)E;
+    }
+    __syncthreads();
+
+    const int64_t nsrc = E * tc;
+    for (int64_t i = threadIdx.x; i < nsrc; i += LDS_THREADS) {
+        const int64_t e = i / tc, kk = i % tc;
+        const int64_t s = (b * E + e) * K + k0 + kk;
+        const int64_t a = index[s] * tc + kk;
+        const float v = Elem<T>::load(src + s);
+        if constexpr (R == GNNOPS_SUM) {
+            atomicAdd(&acc[a], v);
+        } else if constexpr (R == GNNOPS_MEAN) {
+            atomicAdd(&acc[a], v);
+            atomicAdd(&aux[a], 1);
+        } else if constexpr (R == GNNOPS_MUL) {
+            atomic_update(&acc[a], v, [](float x, float y) { return x * y; });
+        } else if constexpr (R == GNNOPS_MIN) {
+            atomic_update(&acc[a], v, [](float x, float y) { return y < x ? y : x; });
+        } else {
+            atomic_update(&acc[a], v, [](float x, float y) { return y > x ? y : x; });
+        }
+    }
+    __syncthreads();
+
+    if constexpr (IS_ARG) {  // smallest position attaining the extremum
+        for (int64_t i = threadIdx.x; i < nsrc; i += LDS_THREADS) {
+            const int64_t e = i / tc, kk = i % tc;
+            const int64_t s = (b * E + e) * K + k0 + kk;
+            const int64_t a = index[s] * tc + kk;
+            if (Elem<T>::load(src + s) == acc[a]) atomicMin(&aux[a], (int)e);
+        }
+        __syncthreads();
+    }
+
+    for (int64_t i = threadIdx.x; i < nacc; i += LDS_THREADS) {
+        const int64_t n = i / tc, kk = i % tc;
+        const int64_t o = (b * N + n) * K + k0 + kk;
+        float v = acc[i];
+        if (R == GNNOPS_MEAN) v = v / (float)(aux[i] < 1 ? 1 : aux[i]);
+        if (IS_ARG) {
+            if (!init_from_out && aux[i] == (int)E) v = 0.f;
+            if (arg_out) arg_out[o] = aux[i];
+        }
+        Elem<T>::store(out + o, v);
+    }
+}
+
+// Returns 0 when the LDS form does not apply (too many destinations per strip), else the strip width.
+inline int lds_strip_width(int64_t N, int64_t K, int reduce) {
+    const size_t per = (reduce == GNNOPS_SUM || reduce == GNNOPS_MUL) ? 4 : 8;
+    if (N <= 0 || (size_t)N * per > LDS_BUDGET) return 0;
+    int64_t tc = (int64_t)(LDS_BUDGET / ((size_t)N * per));
+    if (tc > K) tc = K;
+    if (tc > 64) tc = 64;
+    if (tc >= 4) tc &= ~(int64_t)3;      // whole 8-B / 32-B pieces of a row
+    if (tc < 2 && K >= 2) return 0;       // one-column strips read too little of every line
+    return (int)tc;
+}
+
+template <typename T, int R>
+int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int64_t B, int64_t E, int64_t K, int64_t N,
+               int tc, int init_from_out, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_kernel<T, R>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
+            return gnnops_check_launch("scatter_lds attribute");
+        configured = true;
+    }
+    const size_t per = (R == GNNOPS_SUM || R == GNNOPS_MUL) ? 4 : 8;
+    const int strips = (int)gnnops_cdiv(K, tc);
+    const size_t lds = (size_t)N * tc * per;
+    hipLaunchKernelGGL((scatter_lds_kernel<T, R>), dim3((unsigned)(B * strips)), dim3(LDS_THREADS), lds, stream, src, index,
+                       out, arg_out, B, E, K, N, tc, strips, init_from_out);
+    return gnnops_check_launch("scatter_lds");
+}
+
+template <typename T>
+int dispatch_lds(int reduce, const T* src, const int64_t* index, T* out, int64_t* arg_out, int64_t B, int64_t E,
+                 int64_t K, int64_t N, int tc, int init_from_out, hipStream_t stream) {
+    switch (reduce) {
+        case GNNOPS_SUM: return launch_lds<T, GNNOPS_SUM>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
+        case GNNOPS_MEAN: return launch_lds<T, GNNOPS_MEAN>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
+        case GNNOPS_MUL: return launch_lds<T, GNNOPS_MUL>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
+        case GNNOPS_MIN: return launch_lds<T, GNNOPS_MIN>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
+        case GNNOPS_MAX: return launch_lds<T, GNNOPS_MAX>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
+    }
+    return GNNOPS_EINVAL;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int grid_for(int64_t n) { return gnnops_grid_cap(gnnops_cdiv(n, 256), 256 * 16); }
 
@@ -156,6 +277,10 @@ int run(const void* src_, const int64_t* index, void* out_, int64_t* arg_out, in
     const int gs = grid_for(nsrc), go = grid_for(nout);
     constexpr bool IS_F32 = sizeof(T) == 4;
     char* w = (char*)workspace;
+
+    if (const int tc = lds_strip_width(N, K, reduce); tc > 0 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31) &&
+        E < ((int64_t)1 << 31))
+        return dispatch_lds<T>(reduce, src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
 
     if (reduce == GNNOPS_SUM || reduce == GNNOPS_MEAN || reduce == GNNOPS_MUL) {
         // fp32 accumulator: `out` itself for fp32, a scratch for 16-bit types (rounded once at the end)

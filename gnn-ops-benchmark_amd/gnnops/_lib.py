@@ -38,7 +38,8 @@ SIGNATURES = {
     "gnnops_spspmm_workspace_bytes": (_sz, [_i64]),
     "gnnops_spspmm_count": (_ci, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "gnnops_spspmm_expand": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp]),
-    "gnnops_addmm": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp]),
+    "gnnops_addmm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gnnops_addmm": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
     "gnnops_fused_index_add_select_sum_workspace_bytes": (_sz, [_i64, _i64]),
     "gnnops_fused_index_add_select_sum": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
 }

@@ -475,9 +475,12 @@ def addmm(input, mat1, mat2, *, beta=1, alpha=1):
     mat1 = mat1.contiguous()
     mat2 = mat2.contiguous()
     out = torch.empty((M, N), dtype=mat1.dtype, device=mat1.device)
+    L = _lib.load()
+    ws_bytes = L.gnnops_addmm_workspace_bytes(M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat1.device) if ws_bytes else None
     with torch.cuda.device(mat1.device):
-        rc = _lib.load().gnnops_addmm(input.data_ptr() if input is not None else None, mat1.data_ptr(), mat2.data_ptr(),
-                                      out.data_ptr(), M, N, K, dt, _stream())
+        rc = L.gnnops_addmm(input.data_ptr() if input is not None else None, mat1.data_ptr(), mat2.data_ptr(),
+                            out.data_ptr(), M, N, K, dt, ws.data_ptr() if ws is not None else None, ws_bytes, _stream())
     check(rc, "addmm")
     return out
 
