@@ -76,7 +76,8 @@ def main():
     gnnops.set_plan_cache(False)
 
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("GNNOPS_BENCH_FORCE_DIST") == "1"  # 1-rank rehearsal of the RCCL path
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
@@ -86,10 +87,10 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
     src = torch.rand(E, D, generator=gen, device=dev, dtype=torch.float32)
     index = torch.randint(0, Ntot, (E,), generator=gen, device=dev, dtype=torch.int64)
-    slab = torch.empty(Nloc, D, device=dev, dtype=torch.float32) if world > 1 else None
+    slab = torch.empty(Nloc, D, device=dev, dtype=torch.float32) if dist is not None else None
 
     def step():
-        if world == 1:
+        if dist is None:
             return gnnops.scatter_add(src, index, dim=0, dim_size=Ntot)
         from gnnops.dist import sharded_scatter
 
@@ -143,8 +144,15 @@ def main():
         result["warm"] = warm_leg(torch, gnnops, src, index, Ntot, E, D, args.steps)
         if not args.no_extra_ops:
             result["ops"] = extra_ops(torch, gnnops, src, index, Ntot, E, D)
+        del out
+        if not args.no_extra_ops and args.workload == "c2":
+            del src, index
+            torch.cuda.empty_cache()
+            result["config3"] = config3_leg(torch, gnnops)
+            torch.cuda.empty_cache()
+            result["config4"] = config4_leg(torch, gnnops)
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
-            del out
             result["cpu_baseline"] = cpu_baseline_leg(D)
     if rank == 0:
         print(json.dumps(result))
@@ -243,6 +251,67 @@ def extra_ops(torch, gnnops, src, index, N, E, D):
     finally:
         _ops._PUSH_MIN_TABLE_BYTES = saved
     return res
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 (MI355X_MICROARCH.md)
+
+
+def config3_leg(torch, gnnops):
+    """BASELINE configs[2]: spmm over CSR 2M x 2M, nnz 40M, D=256 bf16 + addmm (GNN shape and square)."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(42)
+    M, nnz, D = 2_000_000, 40_000_000, 256
+    row = torch.randint(0, M, (nnz,), generator=g, device=dev).sort().values
+    col = torch.randint(0, M, (nnz,), generator=g, device=dev)
+    rowptr = torch.zeros(M + 1, dtype=torch.int32, device=dev)
+    rowptr[1:] = torch.bincount(row, minlength=M).cumsum(0).to(torch.int32)
+    del row
+    val = torch.rand(nnz, generator=g, device=dev).to(torch.bfloat16)
+    Bm = torch.rand(M, D, generator=g, device=dev).to(torch.bfloat16)
+    ms = _event_ms(torch, lambda: gnnops.spmm_csr(rowptr, col, val, Bm), 5)
+    alg = nnz * (8 + 2) + (M + 1) * 8 + M * D * 2 + M * D * 2      # SURVEY.md 8(d): 2.464 GB
+    gathered = nnz * D * 2
+    res = {"spmm_csr_bf16": {"ms": round(ms, 4), "alg_GBps": round(alg / ms / 1e6, 1), "gathered_GBps": round(gathered / ms / 1e6, 1),
+                             "pct_of_hbm_peak_alg": round(alg / ms / 1e6 / HBM_PEAK_GBS * 100, 2),
+                             "GFLOPs": round(2 * nnz * D / ms / 1e6, 1)}}
+    del col, val
+    W = torch.rand(D, D, generator=g, device=dev).to(torch.bfloat16)
+    ms = _event_ms(torch, lambda: gnnops.addmm(Bm, Bm, W), 5)
+    fl = 2 * M * D * D
+    res["addmm_gnn_shape_bf16"] = {"shape": f"[{M},{D}] + [{M},{D}]@[{D},{D}]", "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1),
+                                   "alg_GBps": round((3 * M * D * 2 + D * D * 2) / ms / 1e6, 1)}
+    del Bm, W
+    L = 8192
+    a = (torch.rand(L, L, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+    b = (torch.rand(L, L, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+    c = (torch.rand(L, L, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+    ms = _event_ms(torch, lambda: gnnops.addmm(c, a, b), 10)
+    res["addmm_square_bf16"] = {"shape": f"{L}^3", "ms": round(ms, 4), "TFLOPs": round(2 * L ** 3 / ms / 1e9, 1),
+                                "mfma_frac_of_dense_peak": round(2 * L ** 3 / ms / 1e9 / MFMA_PEAK_TFLOPS, 4)}
+    return res
+
+
+def config4_leg(torch, gnnops):
+    """BASELINE configs[3]: fused index_select+sum vs the unfused pair, E=100M, D=128 fp16 (N=E, RF 1)."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(42)
+    E, D = 100_000_000, 128
+    table = torch.empty(E, D, device=dev, dtype=torch.float16).uniform_(0, 1, generator=g)
+    index = torch.randint(0, E, (E,), generator=g, device=dev)
+    fused = _event_ms(torch, lambda: gnnops.index_select_sum(table, 0, index), 3)
+
+    def unfused():
+        sel = gnnops.index_select(table, 0, index)        # our pull kernel, [E,D] materialised
+        return sel.sum(dtype=torch.float32)               # torch reduction with an fp32 accumulator
+
+    unf = _event_ms(torch, unfused, 2)
+    alg_f = E * 8 + E * D * 2
+    alg_u = E * 8 + 3 * E * D * 2
+    return {"fused_ms": round(fused, 4), "fused_alg_GBps": round(alg_f / fused / 1e6, 1),
+            "fused_pct_of_hbm_peak": round(alg_f / fused / 1e6 / HBM_PEAK_GBS * 100, 2),
+            "unfused_ms": round(unf, 4), "unfused_alg_GBps": round(alg_u / unf / 1e6, 1),
+            "speedup": round(unf / fused, 2),
+            "note": "unfused = gnnops.index_select (materialises [E,D]) + torch sum(dtype=float32); fp32 accumulators compared"}
 
 
 def cpu_baseline_leg(D):

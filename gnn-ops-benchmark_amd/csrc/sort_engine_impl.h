@@ -159,13 +159,18 @@ __global__ __launch_bounds__(THREADS, (sizeof(typename KA::Carry) == 4 ? 4 : 2))
         const int64_t i = wave_base + r * 64 + lane;
         const bool valid = i < n;
         const uint32_t d = KA::digit(key[r], shift);
-        uint64_t m = __ballot(valid);
+        // peers = lanes whose digit equals mine: AND over the 8 digit bits of (ballot(bit) XNOR my bit).
+        // Written on 32-bit halves with a sign-extended bit so each step is one 3-input boolean op.
+        const uint64_t vb = __ballot(valid);
+        uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+            const uint32_t x = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // all ones if the bit is set
+            const uint64_t bal = __ballot(x != 0u);
+            m_lo &= ~((uint32_t)bal ^ x);
+            m_hi &= ~((uint32_t)(bal >> 32) ^ x);
         }
+        const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
         const uint32_t below = __popcll(m & lanes_below);
         if (valid && below == 0) {
             x[r] = atomicAdd(&whist[d], (uint32_t)__popcll(m));
