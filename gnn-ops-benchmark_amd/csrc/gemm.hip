@@ -2,18 +2,18 @@
 // (reference: op_bm_scripts/benchmark_native_addmm.py:13-16, benchmark_native_matmul.py:13-16; fp16 square
 // L in [1581, 8164]; BASELINE config 3 asks for bf16). out = input + mat1 @ mat2, fp32 accumulate, one
 // rounding. This is the one row of the hot path that is a real contraction, so it runs on the matrix
-// cores: v_mfma_f32_16x16x32_{bf16,f16}, 64-lane waves, LDS-staged 128 x 128 x 32 tiles.
+// cores: v_mfma_f32_16x16x32_{bf16,f16}, 64-lane waves, LDS-staged 128 x 128 x 64 tiles.
 //
 // Layout (row-major operands, as torch hands them over):
-//   A tile [128][32] in LDS with 80-byte rows; a lane's A fragment (row l&15, k = 8*(l>>4)..+7) is one
-//     ds_read_b128.
-//   B tile [32][128] stays ROW-major in LDS (coalesced 16-B global loads, no transposing writes); the
-//     k-strided B fragment comes from two ds_read_b64_tr_b16 hardware-transpose reads (4 k-rows x 16
-//     columns per 16-lane group each).
-//   4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles (64 accumulator VGPRs); next tile's global loads
-//     are issued before the MFMA block of the current one.
-// First version: single LDS buffer, two barriers per K-step (the guide's "step-3" structure, ~1/3 of
-// the MFMA roof); the deeper 256^2 pipeline is the follow-up. Operands whose row length is not a multiple of
+//   A tile [128][64] in LDS, 128-B rows, 16-B chunks XOR-swizzled by (row & 7); a lane's A fragment (row l&15,
+//     k = 8*(l>>4)..+7) is one conflict-free ds_read_b128.
+//   B tile [64][128] stays ROW-major in LDS (coalesced 16-B global loads, no transposing writes) in the
+//     guide's swizzled 256-B-row image; the k-strided B fragment comes from two ds_read_b64_tr_b16
+//     hardware-transpose reads (4 k-rows x 16 columns per 16-lane group each).
+//   4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles (64 accumulator VGPRs). Two LDS stages: the next tile is
+//     loaded to registers before, and stored to the other stage after, the 32 MFMAs of the current one — one
+//     barrier per K-step. The epilogue parks each wave's fp32 tile in LDS and writes 16-B row pieces.
+// Still a register-staged pipeline (~0.3 of the MFMA roof); LDS-DMA staging with counted waits is the follow-up. Operands whose row length is not a multiple of
 // 8 elements (the reference sweeps L = 1581 ... 8164) are first copied into 16-B aligned, zero-padded rows
 // (pad_rows_kernel, workspace), so the staging loads are always 16-B vectors.
 #include "common.h"
@@ -26,9 +26,11 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int AS = 40;   // A row stride in elements (80 B: 16-B aligned, breaks the 64-B power-of-two stride)
-constexpr int BS = 136;  // B row stride in elements (272 B)
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int A_TILE_BYTES = BM * BK * 2;              // 16 KiB, 128-B rows, 8 chunks of 16 B
+constexpr int B_TILE_BYTES = BK * BN * 2;              // 16 KiB, 256-B rows, 16 chunks of 16 B
+constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+constexpr int CS = 68;                                  // epilogue row stride in floats (64 + 4)
 
 template <bool IS_BF16>
 __device__ inline f32x4 mfma16(const s16x8& a, const s16x8& b, const f32x4& c) {
@@ -38,29 +40,45 @@ __device__ inline f32x4 mfma16(const s16x8& a, const s16x8& b, const f32x4& c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// 8 consecutive 16-bit elements of row `r`, columns c..c+7 of a [rows][cols] row-major matrix (leading dim ld);
-// out-of-range elements read as 0. vec_ok: ld % 8 == 0 and 16-B aligned base.
-__device__ inline u32x4 load8(const uint16_t* __restrict__ base, int64_t r, int64_t c, int64_t rows, int64_t cols,
-                              int64_t ld, bool vec_ok) {
+// XOR swizzles (byte offsets inside a tile). A: chunk ^ (row & 7) makes the ds_read_b128 of 16 rows x one
+// k-chunk conflict-free; B: the guide's 256-B-row image (cdna_hip_programming.md T10 (b)), conflict-free for
+// ds_read_b64_tr_b16.
+__device__ inline int a_off(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
+__device__ inline int b_off(int row, int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+// 8 consecutive 16-bit elements of row `r`, columns c..c+7 of a [rows][cols] row-major matrix whose rows start
+// ALIGN-byte aligned (cols * 2 % ALIGN == 0): ALIGN = 16 -> one dwordx4, 8 -> two dwordx2, 4 -> four dwords.
+// A piece never straddles the row end; pieces beyond it, and rows beyond `rows`, read as 0.
+template <int ALIGN>
+__device__ inline u32x4 load8(const uint16_t* __restrict__ base, int64_t r, int64_t c, int64_t rows, int64_t cols) {
     u32x4 v = {0u, 0u, 0u, 0u};
     if (r >= rows || c >= cols) return v;
-    const uint16_t* p = base + r * ld + c;
-    if (vec_ok && c + 8 <= ld) return *reinterpret_cast<const u32x4*>(p);  // ld % 8 == 0; padded tail is zero
-    uint16_t e[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = (c + i < cols) ? p[i] : (uint16_t)0;
-    v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
-    v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+    const uint16_t* p = base + r * cols + c;
+    if constexpr (ALIGN == 16) {
+        v = *reinterpret_cast<const u32x4*>(p);
+    } else if constexpr (ALIGN == 8) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(p);
+        v.x = lo.x; v.y = lo.y;
+        if (c + 4 < cols) { const uint2 hi = *reinterpret_cast<const uint2*>(p + 4); v.z = hi.x; v.w = hi.y; }
+    } else {
+        v.x = *reinterpret_cast<const uint32_t*>(p);
+        if (c + 2 < cols) v.y = *reinterpret_cast<const uint32_t*>(p + 2);
+        if (c + 4 < cols) v.z = *reinterpret_cast<const uint32_t*>(p + 4);
+        if (c + 6 < cols) v.w = *reinterpret_cast<const uint32_t*>(p + 6);
+    }
     return v;
 }
 
-template <typename T, bool IS_BF16>
-__global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
-                                                   const T* __restrict__ addend, T* __restrict__ C, int64_t M,
-                                                   int64_t N, int64_t K, int64_t lda, int64_t ldb, bool a_vec,
-                                                   bool b_vec) {
-    __shared__ __attribute__((aligned(16))) uint16_t sA[BM * AS];
-    __shared__ __attribute__((aligned(16))) uint16_t sB[BK * BS];
+// out = addend + A @ B. A [M, K] and B [K, N] row-major with ALIGN-byte aligned rows (the host copies an operand
+// with an odd row length into padded rows first).
+template <typename T, bool IS_BF16, int ALIGN>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
+                                                      const T* __restrict__ addend, T* __restrict__ C, int64_t M,
+                                                      int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    // lda / ldb = row lengths as stored (== K / N unless the host padded them); they bound the column reads
+    constexpr int EPI_BYTES = 4 * 64 * CS * 4;  // four waves' fp32 tiles
+    constexpr int SMEM_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];  // 68 KiB: two stages; epilogue reuses it
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -72,86 +90,178 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging coordinates: two 16-B pieces of A and of B per thread and K-step
-    const int a_row[2] = {tid >> 2, (tid + 256) >> 2};
-    const int a_chk = tid & 3;
-    const int b_row[2] = {tid >> 4, (tid + 256) >> 4};
-    const int b_chk = tid & 15;
-
-    u32x4 ra[2], rb[2];
+    // staging: 4 chunks of A and 4 of B per thread and K-step; chunk id = tid + 256*p
+    int a_st[4], b_st[4];          // swizzled LDS byte offsets (within a stage)
+    int64_t a_gr[4], b_gr[4];      // global row of each chunk
+    int a_gc[4], b_gc[4];          // global column (elements) inside the tile
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int id = tid + 256 * p;
+        const int ar = id >> 3, ac = id & 7;     // A: 128 rows x 8 chunks
+        a_st[p] = a_off(ar, ac);
+        a_gr[p] = m0 + ar;
+        a_gc[p] = ac * 8;
+        const int br = id >> 4, bc = id & 15;    // B: 64 rows x 16 chunks
+        b_st[p] = A_TILE_BYTES + b_off(br, bc);
+        b_gr[p] = br;
+        b_gc[p] = bc * 8;
+    }
+    u32x4 ra[4], rb[4];
     auto gload = [&](int64_t k0) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            ra[p] = load8(A, m0 + a_row[p], k0 + a_chk * 8, M, K, lda, a_vec);
-            rb[p] = load8(Bm, k0 + b_row[p], n0 + b_chk * 8, K, N, ldb, b_vec);
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = load8<ALIGN>(A, a_gr[p], k0 + a_gc[p], M, lda);
+            rb[p] = load8<ALIGN>(Bm, k0 + b_gr[p], n0 + b_gc[p], K, ldb);
+        }
+    };
+    auto sstore = [&](int stage) {
+        unsigned char* base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<u32x4*>(base + a_st[p]) = ra[p];
+            *reinterpret_cast<u32x4*>(base + b_st[p]) = rb[p];
         }
     };
 
-    // fragment read addresses (constant over the K loop)
-    const int a_off = (wr * 64 + (lane & 15)) * AS + (lane >> 4) * 8;                      // + mi*16*AS
-    const int b_off = (8 * (lane >> 4) + ((lane & 15) >> 2)) * BS + wc * 64 + 4 * (lane & 3);  // + ni*16, + 4*BS
+    // fragment addresses. A: row = wr*64 + mi*16 + (lane&15), chunk = ks*4 + (lane>>4).
+    // B (transposed read): 16-lane group g = lane>>4 owns k rows ks*32 + 8g (+4 for the second read); lane 4q+p
+    // supplies row +q, chunk c0 + (p>>1), +8 bytes for odd p; c0 = 2 * (16-column block) = wc*8 + ni*2.
+    const int a_row = wr * 64 + (lane & 15);
+    const int a_kc = lane >> 4;
+    const int b_q = (lane & 15) >> 2, b_p = lane & 3;
+    const int b_row = 8 * (lane >> 4) + b_q;
 
+    const int64_t ksteps = (K + BK - 1) / BK;
     gload(0);
-    for (int64_t k0 = 0; k0 < K; k0 += BK) {
-        __syncthreads();  // everyone has finished reading the previous tile
+    sstore(0);
+    __syncthreads();
+    for (int64_t kt = 0; kt < ksteps; ++kt) {
+        const int cur = (int)(kt & 1);
+        const bool more = kt + 1 < ksteps;
+        if (more) gload((kt + 1) * BK);
+        const unsigned char* sA = smem + cur * STAGE_BYTES;
+        const unsigned char* sB = sA + A_TILE_BYTES;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            *reinterpret_cast<u32x4*>(&sA[a_row[p] * AS + a_chk * 8]) = ra[p];
-            *reinterpret_cast<u32x4*>(&sB[b_row[p] * BS + b_chk * 8]) = rb[p];
+        for (int ks = 0; ks < 2; ++ks) {
+            s16x8 af[4], bf[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                af[mi] = *reinterpret_cast<const s16x8*>(sA + a_off(a_row + mi * 16, ks * 4 + a_kc));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int ch = wc * 8 + ni * 2 + (b_p >> 1);
+                const int r_lo = ks * 32 + b_row;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sB + b_off(r_lo, ch) + 8 * (b_p & 1)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sB + b_off(r_lo + 4, ch) + 8 * (b_p & 1)));
+                bf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
         }
+        if (more) sstore(cur ^ 1);
         __syncthreads();
-        if (k0 + BK < K) gload(k0 + BK);
-
-        s16x8 af[4], bf[4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const s16x8*>(&sA[a_off + mi * 16 * AS]);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(&sB[b_off + ni * 16]));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(&sB[b_off + ni * 16 + 4 * BS]));
-            bf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
     }
 
-    // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // Epilogue through LDS: each wave parks its 64 x 64 fp32 tile (C/D map: col = lane & 15, row = (lane >> 4)*4 + reg),
+    // then reads whole row pieces back: 8 lanes x 8 columns per row, so the addend load and the store are 16-B
+    // accesses on 128-B row segments. One rounding, after the add.
+    float* ctile = reinterpret_cast<float*>(smem) + wave * (64 * CS);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = m0 + wr * 64 + mi * 16 + (lane >> 4) * 4 + r;
-                const int64_t col = n0 + wc * 64 + ni * 16 + (lane & 15);
-                if (row < M && col < N) {
-                    float v = acc[mi][ni][r];
-                    if (addend) v += Elem<T>::load(addend + row * N + col);
-                    Elem<T>::store(C + row * N + col, v);
+            for (int r = 0; r < 4; ++r)
+                ctile[(mi * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+    __builtin_amdgcn_wave_barrier();  // the tile is private to this wave; LDS ops of one wave complete in order
+    const bool vec_c = (N % 8 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
+    const int pr = lane >> 3, pc = (lane & 7) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int rr = pass * 8 + pr;
+        const int64_t row = m0 + wr * 64 + rr;
+        const int64_t col = n0 + wc * 64 + pc;
+        float f[8];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        if (row >= M || col >= N) continue;
+        const bool half_c = (N % 4 == 0) && ((uintptr_t)C % 8 == 0) && (addend == nullptr || (uintptr_t)addend % 8 == 0);
+        if (vec_c && col + 8 <= N) {
+            if (addend) {
+                float g[8];
+                Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + row * N + col), g);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] += g[i];
+            }
+            *reinterpret_cast<u32x4*>(C + row * N + col) = Elem<T>::pack(f);
+        } else if (half_c) {  // rows 8-B aligned (N % 4 == 0): two 4-element pieces, each whole or absent
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (col + 4 * h < N) {
+                    float* fh = f + 4 * h;
+                    if (addend) {
+                        const uint2 g2 = *reinterpret_cast<const uint2*>(addend + row * N + col + 4 * h);
+                        float g[8];
+                        Elem<T>::unpack(u32x4{g2.x, g2.y, 0u, 0u}, g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fh[i] += g[i];
+                    }
+                    float tmp[8] = {fh[0], fh[1], fh[2], fh[3], 0.f, 0.f, 0.f, 0.f};
+                    const u32x4 pk = Elem<T>::pack(tmp);
+                    *reinterpret_cast<uint2*>(C + row * N + col + 4 * h) = uint2{pk.x, pk.y};
                 }
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (col + i < N) {
+                    float v = f[i];
+                    if (addend) v += Elem<T>::load(addend + row * N + col + i);
+                    Elem<T>::store(C + row * N + col + i, v);
+                }
+            }
+        }
+    }
 }
 
 // Copy a [rows][cols] 16-bit matrix into rows of `ld` elements (ld % 8 == 0), zero-filling the tail, so that every
 // row starts 16-B aligned and the GEMM's 16-B staging loads apply (the reference sweeps odd sizes: L = 1581...).
+template <int ALIGN>
 __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                 int64_t ld) {
     const int64_t chunks = ld / 8, total = rows * chunks;  // one 16-B output chunk per thread
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / chunks, c = (i % chunks) * 8;
-        const uint16_t* p = in + r * cols + c;
-        uint16_t e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = (c + j < cols) ? p[j] : (uint16_t)0;
         u32x4 v;
-        v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
-        v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+        if constexpr (ALIGN >= 4) {
+            v = load8<ALIGN>(in, r, c, rows, cols);
+        } else {
+            const uint16_t* p = in + r * cols + c;
+            uint16_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = (c + j < cols) ? p[j] : (uint16_t)0;
+            v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+            v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+        }
         *reinterpret_cast<u32x4*>(out + r * ld + c) = v;
     }
+}
+
+inline void launch_pad(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld, hipStream_t stream) {
+    const dim3 grid(gnnops_grid_cap(gnnops_cdiv(rows * ld / 8, 256), 256 * 16));
+    const uint16_t* i = (const uint16_t*)in;
+    uint16_t* o = (uint16_t*)out;
+    if (cols % 4 == 0 && (uintptr_t)in % 8 == 0)
+        hipLaunchKernelGGL(pad_rows_kernel<8>, grid, dim3(256), 0, stream, i, o, rows, cols, ld);
+    else if (cols % 2 == 0 && (uintptr_t)in % 4 == 0)
+        hipLaunchKernelGGL(pad_rows_kernel<4>, grid, dim3(256), 0, stream, i, o, rows, cols, ld);
+    else
+        hipLaunchKernelGGL(pad_rows_kernel<2>, grid, dim3(256), 0, stream, i, o, rows, cols, ld);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -183,25 +293,23 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
     char* w = (char*)workspace;
     if (K % 8 && K > 0) {
         lda = round8(K);
-        hipLaunchKernelGGL(pad_rows_kernel, dim3(gnnops_grid_cap(gnnops_cdiv(M * lda / 8, 256), 256 * 16)), dim3(256), 0, stream,
-                           (const uint16_t*)mat1, (uint16_t*)w, M, K, lda);
+        launch_pad(mat1, w, M, K, lda, stream);
         mat1 = w;
         w += align_up((size_t)M * lda * 2, 256);
     }
     if (N % 8 && K > 0) {
         ldb = round8(N);
-        hipLaunchKernelGGL(pad_rows_kernel, dim3(gnnops_grid_cap(gnnops_cdiv(K * ldb / 8, 256), 256 * 16)), dim3(256), 0, stream,
-                           (const uint16_t*)mat2, (uint16_t*)w, K, N, ldb);
+        launch_pad(mat2, w, K, N, ldb, stream);
         mat2 = w;
     }
-    const bool a_vec = (uintptr_t)mat1 % 16 == 0;
-    const bool b_vec = (uintptr_t)mat2 % 16 == 0;
+    GNNOPS_REQUIRE(K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0), GNNOPS_EUNSUPPORTED,
+                   "addmm: operand base pointers must be 16-byte aligned");
     dim3 grid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
     if (dtype == GNNOPS_BF16)
-        hipLaunchKernelGGL((gemm_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                           (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb, a_vec, b_vec);
+        hipLaunchKernelGGL((gemm_kernel<__hip_bfloat16, true, 16>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
+                           (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb);
     else
-        hipLaunchKernelGGL((gemm_kernel<__half, false>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                           (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb, a_vec, b_vec);
+        hipLaunchKernelGGL((gemm_kernel<__half, false, 16>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
+                           (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb);
     return gnnops_check_launch("addmm");
 }
