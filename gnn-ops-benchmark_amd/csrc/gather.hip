@@ -103,6 +103,65 @@ __global__ __launch_bounds__(256) void select_elems_kernel(const U* __restrict__
     }
 }
 
+// LDS-staged element form: a workgroup owns one (b, column strip of TC columns), parks input[b, :, strip] in
+// LDS (N * TC elements, coalesced along the strip) and serves every selected element from there, so the
+// reads of `input` are sequential and each output element is one LDS read + one coalesced store. Covers what
+// the row form cannot: K == 1 (index_select / gather along the last dim of a matrix, the reference's dim-1
+// sweeps) and gather along dim 0 with its per-element index (benchmark_native_gather.py:68-73).
+constexpr int GL_THREADS = 1024;
+constexpr size_t GL_BUDGET = 160 * 1024 - 512;
+
+template <typename U, bool FULL_INDEX>
+__global__ __launch_bounds__(GL_THREADS) void gather_lds_kernel(const U* __restrict__ in, const int64_t* __restrict__ index,
+                                                                U* __restrict__ out, int64_t B, int64_t N, int64_t K,
+                                                                int64_t E, int TC, int strips) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gl_raw[];
+    U* tile = reinterpret_cast<U*>(gl_raw);
+    const int64_t b = blockIdx.x / strips;
+    const int64_t k0 = (int64_t)(blockIdx.x % strips) * TC;
+    const int tc = (int)((K - k0 < TC) ? (K - k0) : TC);
+    const int64_t nin = N * tc;
+    for (int64_t i = threadIdx.x; i < nin; i += GL_THREADS) {
+        const int64_t n = i / tc, kk = i % tc;
+        tile[i] = in[(b * N + n) * K + k0 + kk];
+    }
+    __syncthreads();
+    const int64_t nout = E * tc;
+    for (int64_t i = threadIdx.x; i < nout; i += GL_THREADS) {
+        const int64_t e = i / tc, kk = i % tc;
+        const int64_t o = (b * E + e) * K + k0 + kk;
+        const int64_t n = FULL_INDEX ? index[o] : index[e];
+        out[o] = tile[n * tc + kk];
+    }
+}
+
+inline int gather_lds_width(int64_t N, int64_t K, int64_t E, int elem_bytes) {
+    if (N <= 0 || (size_t)N * elem_bytes > GL_BUDGET) return 0;
+    int64_t tc = (int64_t)(GL_BUDGET / ((size_t)N * elem_bytes));
+    if (tc > K) tc = K;
+    if (tc > 64) tc = 64;
+    if (tc >= 8) tc &= ~(int64_t)7;
+    if (tc * elem_bytes < 8 && K * elem_bytes >= 8) return 0;  // strips under 8 bytes waste most of every line
+    if (E * 4 < N) return 0;                                    // staging the whole input would cost more than it saves
+    return (int)tc;
+}
+
+template <typename U, bool FULL_INDEX>
+int launch_gather_lds(const void* in, const int64_t* index, void* out, int64_t B, int64_t N, int64_t K, int64_t E, int tc,
+                      hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_lds_kernel<U, FULL_INDEX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL_BUDGET) != hipSuccess)
+            return gnnops_check_launch("gather_lds attribute");
+        configured = true;
+    }
+    const int strips = (int)gnnops_cdiv(K, tc);
+    hipLaunchKernelGGL((gather_lds_kernel<U, FULL_INDEX>), dim3((unsigned)(B * strips)), dim3(GL_THREADS),
+                       (size_t)N * tc * sizeof(U), stream, (const U*)in, index, (U*)out, B, N, K, E, tc, strips);
+    return gnnops_check_launch("gather_lds");
+}
+
 // ---- fused index_select + sum ----
 constexpr int FUSED_BLOCKS = 256 * 8;
 
@@ -235,6 +294,11 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
         hipLaunchKernelGGL((select_rows_kernel<true, true, ROWS_IN_FLIGHT>), dim3(sgrid), dim3(256), 0, stream,
                            (const char*)input, index, (char*)out, B, N, E, rowbytes, g.gshift, g.chunks);
     } else {
+        // a row index with K > 1 is already coalesced along k in the element kernel; LDS staging pays for K == 1 rows
+        if (const int tc = gather_lds_width(N, K, E, elem_bytes);
+            tc > 0 && K * elem_bytes <= 8 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31))
+            return elem_bytes == 4 ? launch_gather_lds<uint32_t, false>(input, index, out, B, N, K, E, tc, stream)
+                                   : launch_gather_lds<uint16_t, false>(input, index, out, B, N, K, E, tc, stream);
         int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
         if (elem_bytes == 4)
             hipLaunchKernelGGL((select_elems_kernel<uint32_t, false>), dim3(grid), dim3(256), 0, stream,
@@ -273,6 +337,9 @@ extern "C" int gnnops_gather(const void* input, const int64_t* index, void* out,
     GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "gather: elem_bytes %d", elem_bytes);
     if (B * E * K == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(input && index && out, GNNOPS_EINVAL, "gather: null pointer");
+    if (const int tc = gather_lds_width(N, K, E, elem_bytes); tc > 0 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31))
+        return elem_bytes == 4 ? launch_gather_lds<uint32_t, true>(input, index, out, B, N, K, E, tc, stream)
+                               : launch_gather_lds<uint16_t, true>(input, index, out, B, N, K, E, tc, stream);
     int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
     if (elem_bytes == 4)
         hipLaunchKernelGGL((select_elems_kernel<uint32_t, true>), dim3(grid), dim3(256), 0, stream,
