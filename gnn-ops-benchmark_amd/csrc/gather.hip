@@ -299,13 +299,18 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
             tc > 0 && K * elem_bytes <= 8 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31))
             return elem_bytes == 4 ? launch_gather_lds<uint32_t, false>(input, index, out, B, N, K, E, tc, stream)
                                    : launch_gather_lds<uint16_t, false>(input, index, out, B, N, K, E, tc, stream);
+        // copy in the widest unit that divides the row and the base alignment (a row is one opaque byte string)
+        const uintptr_t al = (uintptr_t)input | (uintptr_t)out | (uintptr_t)rowbytes;
         int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
-        if (elem_bytes == 4)
+        if (al % 8 == 0)
+            hipLaunchKernelGGL((select_elems_kernel<uint64_t, false>), dim3(grid), dim3(256), 0, stream,
+                               (const uint64_t*)input, index, (uint64_t*)out, B, N, rowbytes / 8, E);
+        else if (al % 4 == 0)
             hipLaunchKernelGGL((select_elems_kernel<uint32_t, false>), dim3(grid), dim3(256), 0, stream,
-                               (const uint32_t*)input, index, (uint32_t*)out, B, N, K, E);
+                               (const uint32_t*)input, index, (uint32_t*)out, B, N, rowbytes / 4, E);
         else
             hipLaunchKernelGGL((select_elems_kernel<uint16_t, false>), dim3(grid), dim3(256), 0, stream,
-                               (const uint16_t*)input, index, (uint16_t*)out, B, N, K, E);
+                               (const uint16_t*)input, index, (uint16_t*)out, B, N, rowbytes / 2, E);
     }
     return gnnops_check_launch("index_select");
 }
