@@ -35,7 +35,8 @@ __global__ void index_max_kernel(const int64_t* __restrict__ index, int64_t E, i
 // that a skewed index (all edges on one node) does not serialise on one lane.
 constexpr int GAP_INLINE = 32;
 
-__global__ void rowptr_kernel(const uint32_t* __restrict__ sorted_keys, int64_t E, int64_t N,
+template <typename KeyT>
+__global__ void rowptr_kernel(const KeyT* __restrict__ sorted_keys, int64_t E, int64_t N,
                               int32_t* __restrict__ rowptr, int32_t* __restrict__ gap_list,
                               unsigned int* __restrict__ gap_count) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= E; i += (int64_t)gridDim.x * blockDim.x) {
@@ -65,11 +66,6 @@ __global__ void fill_gaps_kernel(int32_t* __restrict__ rowptr, const int32_t* __
     }
 }
 
-__global__ void iota_kernel(int32_t* p, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = (int32_t)i;
-}
-
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int key_bits_for(int64_t N) {
@@ -84,11 +80,9 @@ extern "C" int gnnops_index_max(const int64_t* index, int64_t E, int64_t* d_max,
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(d_max != nullptr, GNNOPS_EINVAL, "index_max: d_max is null");
     GNNOPS_REQUIRE(E >= 0 && (E == 0 || index != nullptr), GNNOPS_EINVAL, "index_max: bad index/E");
-    const int64_t init = -1;
-    // d_max = -1, then atomicMax over the data (stream-ordered, no sync)
+    // d_max = -1 (all bits set), then atomicMax over the data (stream-ordered, no sync)
     if (hipMemsetAsync(d_max, 0xff, sizeof(int64_t), stream) != hipSuccess)
         return gnnops_check_launch("index_max memset");
-    (void)init;
     if (E > 0) {
         int grid = gnnops_grid_cap(gnnops_cdiv(E, 256 * 8));
         hipLaunchKernelGGL(index_max_kernel, dim3(grid), dim3(256), 0, stream, index, E, d_max);
@@ -164,8 +158,32 @@ extern "C" int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N, int
         return gnnops_check_launch("plan_build memset gap_count");
     {
         int grid = gnnops_grid_cap(gnnops_cdiv(E + 1, 256));
-        hipLaunchKernelGGL(rowptr_kernel, dim3(grid), dim3(256), 0, stream, sorted_keys, E, N, rowptr, gap_list, gap_count);
+        hipLaunchKernelGGL(rowptr_kernel<uint32_t>, dim3(grid), dim3(256), 0, stream, sorted_keys, E, N, rowptr, gap_list, gap_count);
         hipLaunchKernelGGL(fill_gaps_kernel, dim3(512), dim3(256), 0, stream, rowptr, gap_list, gap_count);
     }
     return gnnops_check_launch("plan_build");
+}
+
+// rowptr of an already sorted int64 index (torch_scatter.segment_coo's input contract; also CSR <- sorted COO rows).
+extern "C" size_t gnnops_rowptr_workspace_bytes(int64_t N) {
+    if (N < 0) return 0;
+    return 256 + align_up(3 * ((size_t)N / GAP_INLINE + 2) * 4, 256);
+}
+
+extern "C" int gnnops_rowptr_from_sorted(const int64_t* sorted_index, int64_t E, int64_t N, int32_t* rowptr,
+                                         void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(E >= 0 && N >= 0 && rowptr, GNNOPS_EINVAL, "rowptr_from_sorted: bad arguments");
+    GNNOPS_REQUIRE(E < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED, "rowptr_from_sorted: E, N must be < 2^31");
+    GNNOPS_REQUIRE(workspace && workspace_bytes >= gnnops_rowptr_workspace_bytes(N), GNNOPS_EWORKSPACE,
+                   "rowptr_from_sorted: workspace too small");
+    GNNOPS_REQUIRE(E == 0 || sorted_index, GNNOPS_EINVAL, "rowptr_from_sorted: null index");
+    unsigned int* gap_count = (unsigned int*)workspace;
+    int32_t* gap_list = (int32_t*)((char*)workspace + 256);
+    if (hipMemsetAsync(gap_count, 0, sizeof(unsigned int), stream) != hipSuccess)
+        return gnnops_check_launch("rowptr_from_sorted memset");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(E + 1, 256));
+    hipLaunchKernelGGL(rowptr_kernel<int64_t>, dim3(grid), dim3(256), 0, stream, sorted_index, E, N, rowptr, gap_list, gap_count);
+    hipLaunchKernelGGL(fill_gaps_kernel, dim3(512), dim3(256), 0, stream, rowptr, gap_list, gap_count);
+    return gnnops_check_launch("rowptr_from_sorted");
 }

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
             int32_t e[U];
             u32x4 rows[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) e[u] = (j + u < end) ? perm[j + u] : -1;
+            for (int u = 0; u < U; ++u) e[u] = (j + u < end) ? (perm ? perm[j + u] : j + u) : -1;
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (e[u] >= 0) rows[u] = load16<NT>(srcb + (int64_t)e[u] * K);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void seg_elems_kernel(const T* __restrict__ sr
         float acc = init_from_out ? Elem<T>::load(out + o) : Red<R>::identity();
         int32_t arg = (int32_t)E;
         for (int32_t j = beg; j < end; ++j) {
-            const int32_t e = perm[j];
+            const int32_t e = perm ? perm[j] : j;
             const float f = Elem<T>::load(srcb + (int64_t)e * K);
             if constexpr (IS_ARG) {
                 if (Red<R>::better(f, acc)) { acc = f; arg = e; }
@@ -201,7 +201,7 @@ extern "C" int gnnops_segment_reduce(const void* src, const int32_t* rowptr, con
     GNNOPS_REQUIRE(!(reduce == GNNOPS_MEAN && init_from_out), GNNOPS_EINVAL,
                    "segment_reduce: mean cannot start from out");
     if (B * N * K == 0) return GNNOPS_OK;
-    GNNOPS_REQUIRE(rowptr && out && (E == 0 || (src && perm)), GNNOPS_EINVAL, "segment_reduce: null pointer");
+    GNNOPS_REQUIRE(rowptr && out && (E == 0 || src), GNNOPS_EINVAL, "segment_reduce: null pointer");
     switch (dtype) {
         case GNNOPS_F32: return dispatch_reduce<float>(reduce, src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, stream);
         case GNNOPS_F16: return dispatch_reduce<__half>(reduce, src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, stream);

@@ -33,6 +33,9 @@ from .ops import (
 )
 from .sparse import (coalesce, coalesce_sparse_tensor, sort, sparse_mm, spmm, spmm_csr, spspmm, transpose,
                      transpose_contiguous)
+from .segment import (gather_coo, gather_csr, rowptr_from_sorted, scatter_log_softmax, scatter_logsumexp, scatter_softmax,
+                      scatter_std, segment_coo, segment_csr)
+from . import autograd
 from .aten import install, uninstall, installed
 
 __all__ = [
@@ -40,5 +43,6 @@ __all__ = [
     "index_add_", "index_max", "index_select", "index_select_sum", "scatter", "scatter_add", "scatter_add_",
     "scatter_max", "scatter_mean", "scatter_min", "scatter_mul", "scatter_reduce_mul_", "scatter_sum",
     "set_plan_cache", "install", "uninstall", "installed", "coalesce", "coalesce_sparse_tensor", "sort", "sparse_mm",
-    "spmm", "spmm_csr", "spspmm", "transpose", "transpose_contiguous", "addmm", "matmul", "index_add_select_sum",
+    "spmm", "spmm_csr", "spspmm", "transpose", "transpose_contiguous", "addmm", "matmul", "index_add_select_sum", "segment_csr", "segment_coo", "gather_csr", "gather_coo",
+    "rowptr_from_sorted", "scatter_softmax", "scatter_log_softmax", "scatter_logsumexp", "scatter_std", "autograd",
 ]

@@ -38,6 +38,9 @@ SIGNATURES = {
     "gnnops_spspmm_workspace_bytes": (_sz, [_i64]),
     "gnnops_spspmm_count": (_ci, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "gnnops_spspmm_expand": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp]),
+    "gnnops_rowptr_workspace_bytes": (_sz, [_i64]),
+    "gnnops_rowptr_from_sorted": (_ci, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "gnnops_segment_composite": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp]),
     "gnnops_addmm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gnnops_addmm": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
     "gnnops_fused_index_add_select_sum_workspace_bytes": (_sz, [_i64, _i64]),

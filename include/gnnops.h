@@ -217,6 +217,26 @@ int gnnops_spspmm_expand(const int64_t* rowA, const int64_t* colA, const void* v
                          int64_t* out_row, int64_t* out_col, void* out_val, int dtype,
                          const void* workspace, gnnops_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Widening per SURVEY.md 8(f) rank 1: what PyG layers on the reference's OpProfiler path call.
+ *
+ * gnnops_segment_reduce with perm == NULL treats rowptr as a CSR pointer over src itself
+ * (torch_scatter.segment_csr); gnnops_rowptr_from_sorted turns a sorted int64 index into that pointer
+ * (torch_scatter.segment_coo's input contract).
+ *
+ * gnnops_segment_composite: torch_scatter.composite over a plan / CSR pointer (perm may be NULL).
+ *   mode 0 softmax      out[B,E,K] = exp(x - max) / sum exp(x - max)
+ *   mode 1 log_softmax  out[B,E,K] = (x - max) - log(sum + param)         param = eps (upstream 1e-12)
+ *   mode 2 logsumexp    out[B,N,K] = max + log(sum + param)               param = eps
+ *   mode 3 std          out[B,N,K] = sqrt(sum (x - mean)^2 / (cnt' + 1e-6)), param != 0: unbiased (cnt' = max(cnt-1,1))
+ * ------------------------------------------------------------------------------------------- */
+size_t gnnops_rowptr_workspace_bytes(int64_t N);
+int gnnops_rowptr_from_sorted(const int64_t* sorted_index, int64_t E, int64_t N, int32_t* rowptr,
+                              void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+int gnnops_segment_composite(const void* src, const int32_t* rowptr, const int32_t* perm, void* out,
+                             int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int mode, double param,
+                             gnnops_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

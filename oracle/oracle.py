@@ -320,3 +320,53 @@ def _narrow(a32, dt):
         return a32.astype(np.float16)
     L = lib()
     return np.array([L.ora_f32_to_bf16(float(v)) for v in a32], dtype=np.uint16)
+
+
+# ---- torch_scatter segment / composite ops -------------------------------------
+def segment_csr(src, indptr, reduce="sum", dtype=None):
+    """torch_scatter.segment_csr for a 1-D indptr along dim 0: scatter with index = segment id of each row."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    index = np.repeat(np.arange(len(indptr) - 1, dtype=np.int64), np.diff(indptr))
+    return scatter(src, index, dim=0, dim_size=len(indptr) - 1, reduce=reduce, dtype=dtype)
+
+
+def _groups(index, N):
+    rowptr, perm = plan(index, N)
+    return [perm[rowptr[n]:rowptr[n + 1]] for n in range(N)]
+
+
+def composite(src, index, N, mode, eps=1e-12, unbiased=True):
+    """scatter_softmax / log_softmax / logsumexp / std along dim 0 of a float32 [E, K] array, restating
+    torch_scatter/composite/{softmax,logsumexp,std}.py (upstream 2.0.9; not in the reference tree): fp32,
+    sequential over each group in source order. exp/log are numpy's, so device parity is to a few ulp."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    E, K = src.shape
+    f32 = np.float32
+    per_source = mode in ("softmax", "log_softmax")
+    out = np.zeros((E, K) if per_source else (N, K), dtype=np.float32)
+    for n, rows in enumerate(_groups(index, N)):
+        x = src[rows]
+        if mode == "std":
+            s = np.zeros(K, f32)
+            for r in x:
+                s = s + r
+            cnt = len(rows)
+            mean = s / f32(max(cnt, 1))
+            var = np.zeros(K, f32)
+            for r in x:
+                d = r - mean
+                var = var + d * d
+            c = max(cnt - 1, 1) if unbiased else max(cnt, 1)
+            out[n] = np.sqrt(var / (f32(c) + f32(1e-6)))
+            continue
+        m = x.max(axis=0) if len(rows) else np.zeros(K, f32)
+        s = np.zeros(K, f32)
+        for r in x:
+            s = s + np.exp(r - m, dtype=f32)
+        if mode == "logsumexp":
+            out[n] = m + np.log(s + f32(eps), dtype=f32)
+        elif mode == "softmax":
+            out[rows] = np.exp(x - m, dtype=f32) / s
+        else:
+            out[rows] = (x - m) - np.log(s + f32(eps), dtype=f32)
+    return out

@@ -162,3 +162,30 @@ def test_oracle_sparse_sort_matches_golden():
     # sort: -0.0 and NaN conventions
     v, i = oracle.sort(np.array([0.0, -0.0, np.nan, -1.0, 0.0], np.float32), 0)
     assert list(i) == [3, 0, 1, 4, 2] and np.isnan(v[-1]) and not np.signbit(v[1])
+
+
+def test_oracle_segment_and_composite_vs_torch_cpu():
+    """The §8(f) restatements against independent torch-CPU formulations (per-group softmax / logsumexp / std)."""
+    g = torch.Generator().manual_seed(9)
+    E, N, K = 600, 50, 5
+    src = torch.randn(E, K, generator=g)
+    idx = torch.randint(0, N, (E,), generator=g)
+    idx[idx == 4] = 5
+    sm = oracle.composite(src.numpy(), idx.numpy(), N, "softmax")
+    lsm = oracle.composite(src.numpy(), idx.numpy(), N, "log_softmax")
+    lse = oracle.composite(src.numpy(), idx.numpy(), N, "logsumexp")
+    sd = oracle.composite(src.numpy(), idx.numpy(), N, "std")
+    for n in range(N):
+        rows = torch.nonzero(idx == n).flatten()
+        if rows.numel() == 0:
+            assert abs(lse[n, 0] - np.log(np.float32(1e-12))) < 1e-3 and (sd[n] == 0).all()
+            continue
+        np.testing.assert_allclose(sm[rows.numpy()], torch.softmax(src[rows], 0).numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(lsm[rows.numpy()], torch.log_softmax(src[rows], 0).numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(lse[n], torch.logsumexp(src[rows], 0).numpy(), rtol=1e-5, atol=1e-6)
+        if rows.numel() > 1:
+            np.testing.assert_allclose(sd[n], src[rows].std(0).numpy(), rtol=1e-4, atol=1e-6)
+    order = torch.sort(idx, stable=True).indices
+    indptr = np.concatenate([[0], np.bincount(idx.numpy(), minlength=N).cumsum()])
+    seg = oracle.segment_csr(src[order].numpy(), indptr, reduce="sum")
+    assert_bits_equal(seg, torch.zeros(N, K).index_add_(0, idx[order], src[order]).numpy(), "segment_csr")
