@@ -158,20 +158,26 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
                                                                   const int64_t* __restrict__ index,
                                                                   T* __restrict__ out, int64_t* __restrict__ arg_out,
                                                                   int64_t B, int64_t E, int64_t K, int64_t N, int TC,
-                                                                  int strips, int init_from_out) {
+                                                                  int strips, int64_t rows, int nchunks,
+                                                                  int init_from_out) {
+    // blockIdx.x = (b * strips + strip) * nchunks + chunk; the chunk owns destinations [n_lo, n_lo + nloc)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* acc = reinterpret_cast<float*>(lds_raw);
-    int* aux = reinterpret_cast<int*>(lds_raw) + (size_t)N * TC;  // counts (MEAN) or arg (MIN/MAX)
+    int* aux = reinterpret_cast<int*>(lds_raw) + (size_t)rows * TC;  // counts (MEAN) or arg (MIN/MAX)
     constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
-    const int64_t b = blockIdx.x / strips;
-    const int64_t k0 = (int64_t)(blockIdx.x % strips) * TC;
+    const int chunk = (int)(blockIdx.x % nchunks);
+    const int64_t bs = blockIdx.x / nchunks;
+    const int64_t b = bs / strips;
+    const int64_t k0 = (int64_t)(bs % strips) * TC;
     const int tc = (int)((K - k0 < TC) ? (K - k0) : TC);
-    const int64_t nacc = N * tc;
+    const int64_t n_lo = (int64_t)chunk * rows;
+    const int64_t nloc = (N - n_lo < rows) ? (N - n_lo) : rows;
+    const int64_t nacc = nloc * tc;
     const float ident = (R == GNNOPS_MUL) ? 1.f : (R == GNNOPS_MIN) ? __builtin_huge_valf()
                         : (R == GNNOPS_MAX) ? -__builtin_huge_valf() : 0.f;
 
     for (int64_t i = threadIdx.x; i < nacc; i += LDS_THREADS) {
-        const int64_t n = i / tc, kk = i % tc;
+        const int64_t n = n_lo + i / tc, kk = i % tc;
         acc[i] = init_from_out ? Elem<T>::load(out + (b * N + n) * K + k0 + kk) : ident;
         if (R == GNNOPS_MEAN) aux[i] = 0;
         if (IS_ARG) aux[i] = (int)E;
@@ -182,7 +188,9 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
     for (int64_t i = threadIdx.x; i < nsrc; i += LDS_THREADS) {
         const int64_t e = i / tc, kk = i % tc;
         const int64_t s = (b * E + e) * K + k0 + kk;
-        const int64_t a = index[s] * tc + kk;
+        const int64_t nl = index[s] - n_lo;
+        if (nl < 0 || nl >= nloc) continue;  // another chunk's destination
+        const int64_t a = nl * tc + kk;
         const float v = Elem<T>::load(src + s);
         if constexpr (R == GNNOPS_SUM) {
             atomicAdd(&acc[a], v);
@@ -203,14 +211,16 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
         for (int64_t i = threadIdx.x; i < nsrc; i += LDS_THREADS) {
             const int64_t e = i / tc, kk = i % tc;
             const int64_t s = (b * E + e) * K + k0 + kk;
-            const int64_t a = index[s] * tc + kk;
+            const int64_t nl = index[s] - n_lo;
+            if (nl < 0 || nl >= nloc) continue;
+            const int64_t a = nl * tc + kk;
             if (Elem<T>::load(src + s) == acc[a]) atomicMin(&aux[a], (int)e);
         }
         __syncthreads();
     }
 
     for (int64_t i = threadIdx.x; i < nacc; i += LDS_THREADS) {
-        const int64_t n = i / tc, kk = i % tc;
+        const int64_t n = n_lo + i / tc, kk = i % tc;
         const int64_t o = (b * N + n) * K + k0 + kk;
         float v = acc[i];
         if (R == GNNOPS_MEAN) v = v / (float)(aux[i] < 1 ? 1 : aux[i]);
@@ -222,21 +232,34 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
     }
 }
 
-// Returns 0 when the LDS form does not apply (too many destinations per strip), else the strip width.
-inline int lds_strip_width(int64_t N, int64_t K, int reduce) {
+// Geometry of the LDS form: strip width TC, destination rows per chunk, chunk count. tc == 0: does not apply.
+// When all N destinations of a strip fit, there is one chunk. Otherwise the destinations are cut into chunks of
+// `rows` and every chunk re-scans the strip's elements, keeping only its own (the (38000, 38000) shapes of
+// data/scatter_max.csv): the re-reads are mostly cache hits and still far cheaper than memory-side atomics.
+struct LdsGeom { int tc; int64_t rows; int nchunks; };
+constexpr int LDS_MAX_CHUNKS = 16;
+
+inline LdsGeom lds_geometry(int64_t N, int64_t K, int reduce) {
     const size_t per = (reduce == GNNOPS_SUM || reduce == GNNOPS_MUL) ? 4 : 8;
-    if (N <= 0 || (size_t)N * per > LDS_BUDGET) return 0;
-    int64_t tc = (int64_t)(LDS_BUDGET / ((size_t)N * per));
-    if (tc > K) tc = K;
-    if (tc > 64) tc = 64;
-    if (tc >= 4) tc &= ~(int64_t)3;      // whole 8-B / 32-B pieces of a row
-    if (tc < 2 && K >= 2) return 0;       // one-column strips read too little of every line
-    return (int)tc;
+    LdsGeom g{0, 0, 0};
+    if (N <= 0) return g;
+    if ((size_t)N * per <= LDS_BUDGET) {
+        int64_t tc = (int64_t)(LDS_BUDGET / ((size_t)N * per));
+        if (tc > K) tc = K;
+        if (tc > 64) tc = 64;
+        if (tc >= 4) tc &= ~(int64_t)3;      // whole 8-B / 32-B pieces of a row
+        if (tc >= 2 || K < 2) return LdsGeom{(int)tc, N, 1};
+    }
+    const int64_t tc = K < 4 ? K : 4;
+    const int64_t rows = (int64_t)(LDS_BUDGET / (per * (size_t)tc));
+    const int64_t nchunks = gnnops_cdiv(N, rows);
+    if (nchunks > LDS_MAX_CHUNKS) return g;  // too many re-scans: memory-side atomics instead
+    return LdsGeom{(int)tc, rows, (int)nchunks};
 }
 
 template <typename T, int R>
 int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int64_t B, int64_t E, int64_t K, int64_t N,
-               int tc, int init_from_out, hipStream_t stream) {
+               LdsGeom g, int init_from_out, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_kernel<T, R>),
@@ -245,22 +268,22 @@ int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int
         configured = true;
     }
     const size_t per = (R == GNNOPS_SUM || R == GNNOPS_MUL) ? 4 : 8;
-    const int strips = (int)gnnops_cdiv(K, tc);
-    const size_t lds = (size_t)N * tc * per;
-    hipLaunchKernelGGL((scatter_lds_kernel<T, R>), dim3((unsigned)(B * strips)), dim3(LDS_THREADS), lds, stream, src, index,
-                       out, arg_out, B, E, K, N, tc, strips, init_from_out);
+    const int strips = (int)gnnops_cdiv(K, g.tc);
+    const size_t lds = (size_t)g.rows * g.tc * per;
+    hipLaunchKernelGGL((scatter_lds_kernel<T, R>), dim3((unsigned)(B * strips * g.nchunks)), dim3(LDS_THREADS), lds, stream,
+                       src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks, init_from_out);
     return gnnops_check_launch("scatter_lds");
 }
 
 template <typename T>
 int dispatch_lds(int reduce, const T* src, const int64_t* index, T* out, int64_t* arg_out, int64_t B, int64_t E,
-                 int64_t K, int64_t N, int tc, int init_from_out, hipStream_t stream) {
+                 int64_t K, int64_t N, LdsGeom g, int init_from_out, hipStream_t stream) {
     switch (reduce) {
-        case GNNOPS_SUM: return launch_lds<T, GNNOPS_SUM>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
-        case GNNOPS_MEAN: return launch_lds<T, GNNOPS_MEAN>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
-        case GNNOPS_MUL: return launch_lds<T, GNNOPS_MUL>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
-        case GNNOPS_MIN: return launch_lds<T, GNNOPS_MIN>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
-        case GNNOPS_MAX: return launch_lds<T, GNNOPS_MAX>(src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
+        case GNNOPS_SUM: return launch_lds<T, GNNOPS_SUM>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MEAN: return launch_lds<T, GNNOPS_MEAN>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MUL: return launch_lds<T, GNNOPS_MUL>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MIN: return launch_lds<T, GNNOPS_MIN>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MAX: return launch_lds<T, GNNOPS_MAX>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
     }
     return GNNOPS_EINVAL;
 }
@@ -278,9 +301,9 @@ int run(const void* src_, const int64_t* index, void* out_, int64_t* arg_out, in
     constexpr bool IS_F32 = sizeof(T) == 4;
     char* w = (char*)workspace;
 
-    if (const int tc = lds_strip_width(N, K, reduce); tc > 0 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31) &&
-        E < ((int64_t)1 << 31))
-        return dispatch_lds<T>(reduce, src, index, out, arg_out, B, E, K, N, tc, init_from_out, stream);
+    if (const LdsGeom g = lds_geometry(N, K, reduce);
+        g.tc > 0 && B * gnnops_cdiv(K, g.tc) * g.nchunks < ((int64_t)1 << 31) && E < ((int64_t)1 << 31))
+        return dispatch_lds<T>(reduce, src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
 
     if (reduce == GNNOPS_SUM || reduce == GNNOPS_MEAN || reduce == GNNOPS_MUL) {
         // fp32 accumulator: `out` itself for fp32, a scratch for 16-bit types (rounded once at the end)

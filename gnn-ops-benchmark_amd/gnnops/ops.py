@@ -226,6 +226,8 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
     want_arg = rcode in (_lib.MIN, _lib.MAX)
     arg = torch.empty(out.shape, dtype=torch.int64, device=src.device) if want_arg else None
 
+    if row_index is not None and not is_plan and (E >= 2 ** 31 or N >= 2 ** 31):
+        row_index = None  # beyond the plan's int32 range: the element-wise kernel takes int64 sizes
     with torch.cuda.device(src.device):
         if row_index is not None:
             plan = get_plan(row_index, N)

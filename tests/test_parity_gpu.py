@@ -168,7 +168,8 @@ def test_scatter_row_index_bit_exact(gnnops, oracle, shape, dim, N, dname):
 @pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("shape,dim,N", [((223, 223), 0, 111), ((223, 223), 1, 27), ((40, 50, 6), 1, 9), ((1000,), 0, 13),
                                          ((3000, 300), 0, 1500),     # LDS form, strips of 12-24 columns
-                                         ((50000, 6), 0, 45000),     # too many destinations for LDS: global atomics
+                                         ((50000, 6), 0, 45000),     # destinations cut into LDS chunks (re-scan form)
+                                         ((700000, 2), 0, 690000),   # too many chunks: global atomics
                                          ((7, 60000), 1, 50000)])    # K == 1, global atomics
 def test_scatter_full_index(gnnops, oracle, shape, dim, N, dname):
     g = torch.Generator().manual_seed(43)
