@@ -3,9 +3,10 @@
 // attention layers (GATv2 softmax, graph_benchmark/models/ptg_models.py:238-258) and PNA aggregators
 // (ptg_models.py:62-78) put on the reference's OpProfiler path (ops.txt:44-50).
 //
-// One thread per output column (b, n, k), coalesced along k; a group's rows are walked two or three times
-// (max / mean, then the shifted sum, then — softmax only — one store per source row); the re-reads hit L1/L2
-// for GNN-sized groups. fp32 arithmetic, sequential over the group in plan order, one rounding on store.
+// Row form: lane group per destination with 16-B lane accesses; groups of <= 8 rows are read once and held in
+// registers across the passes (max / mean, shifted sum, and — softmax only — one store per source row). Element
+// form (any K / alignment): one thread per output column, coalesced along k, rows re-read per pass.
+// fp32 arithmetic, sequential over the group in plan order, one rounding on store.
 //   softmax      out[b,e,k] = exp(x - max_n) / sum_n exp(x - max_n)
 //   log_softmax  out[b,e,k] = (x - max_n) - log(sum_n + eps)
 //   logsumexp    out[b,n,k] = max_n + log(sum_n + eps)          (empty group: max := 0, sum = 0)
@@ -71,9 +72,142 @@ __global__ __launch_bounds__(256) void seg_composite_kernel(const T* __restrict_
     }
 }
 
+// Row form (K % VEC == 0, 16-B aligned): one lane group per destination and 1-KiB column chunk, 16-B lane
+// accesses, U source rows in flight. A group of at most U rows — the common case at GNN degrees — is read ONCE and
+// kept in registers across the two or three logical passes; longer groups re-read their rows chunk by chunk.
+constexpr int U = 8;
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void seg_composite_rows_kernel(const T* __restrict__ src,
+                                                                 const int32_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ perm, T* __restrict__ out,
+                                                                 int64_t B, int64_t E, int64_t K, int64_t N, int gshift,
+                                                                 int kchunks, float param) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int G = 1 << gshift;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
+    const int gl = (int)(gtid & (G - 1));
+    const int64_t items = B * (int64_t)kchunks * N;
+    const float NEG_INF = -__builtin_huge_valf();
+    for (int64_t item = gtid >> gshift; item < items; item += ngroups) {
+        const int64_t n = item % N;
+        const int64_t bc = item / N;
+        const int chunk = (int)(bc % kchunks);
+        const int64_t b = bc / kchunks;
+        const int64_t col = ((int64_t)chunk * G + gl) * VEC;
+        if (col >= K) continue;
+        const int32_t beg = rowptr[n], end = rowptr[n + 1];
+        const bool inreg = (end - beg) <= U;
+        const T* srcb = src + (b * E) * K + col;
+        T* outb = out + (b * E) * K + col;
+        int32_t e[U];
+        u32x4 rows[U];
+        auto load_chunk = [&](int32_t j) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = (j + u < end) ? (perm ? perm[j + u] : j + u) : -1;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e[u] >= 0) rows[u] = *reinterpret_cast<const u32x4*>(srcb + (int64_t)e[u] * K);
+        };
+        float a1[VEC], a2[VEC];  // pass-1 statistic (max or mean) and pass-2 statistic (sum of exp or of squares)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { a1[v] = (MODE == MODE_STD) ? 0.f : NEG_INF; a2[v] = 0.f; }
+
+        for (int32_t j = beg; j < end; j += U) {
+            load_chunk(j);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (e[u] < 0) continue;
+                float f[VEC];
+                Elem<T>::unpack(rows[u], f);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    if (MODE == MODE_STD) a1[v] += f[v];
+                    else a1[v] = f[v] > a1[v] ? f[v] : a1[v];
+                }
+            }
+        }
+        const int32_t cnt = end - beg;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            if (MODE == MODE_STD) a1[v] = a1[v] / (float)(cnt < 1 ? 1 : cnt);
+            else if (cnt == 0) a1[v] = 0.f;
+        }
+        for (int32_t j = beg; j < end; j += U) {
+            if (!inreg) load_chunk(j);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (e[u] < 0) continue;
+                float f[VEC];
+                Elem<T>::unpack(rows[u], f);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float d = f[v] - a1[v];
+                    if (MODE == MODE_STD) {
+                        a2[v] += d * d;
+                    } else {
+                        if (d != d) d = NEG_INF;
+                        a2[v] += expf(d);
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == MODE_STD || MODE == MODE_LOGSUMEXP) {
+            float r[VEC];
+            int32_t c = (MODE == MODE_STD && param != 0.f) ? cnt - 1 : cnt;
+            if (c < 1) c = 1;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                r[v] = (MODE == MODE_STD) ? sqrtf(a2[v] / ((float)c + 1e-6f)) : a1[v] + logf(a2[v] + param);
+            store16<true>(out + (b * N + n) * K + col, Elem<T>::pack(r));
+        } else {
+            float lg[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) lg[v] = logf(a2[v] + param);
+            for (int32_t j = beg; j < end; j += U) {
+                if (!inreg) load_chunk(j);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (e[u] < 0) continue;
+                    float f[VEC];
+                    Elem<T>::unpack(rows[u], f);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        float d = f[v] - a1[v];
+                        if (d != d) d = NEG_INF;
+                        f[v] = (MODE == MODE_SOFTMAX) ? expf(d) / a2[v] : d - lg[v];
+                    }
+                    store16<true>(outb + (int64_t)e[u] * K, Elem<T>::pack(f));
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 int dispatch(int mode, const void* src, const int32_t* rowptr, const int32_t* perm, void* out, int64_t B, int64_t E,
              int64_t K, int64_t N, float param, hipStream_t stream) {
+    constexpr int VEC = Elem<T>::VEC;
+    if (K % VEC == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)out % 16 == 0) {
+        const int64_t vecs = K / VEC;
+        int gshift = 0;
+        while ((1 << gshift) < vecs && gshift < 6) ++gshift;
+        const int kchunks = (int)gnnops_cdiv(vecs, (int64_t)1 << gshift);
+        const int rgrid = gnnops_grid_cap(gnnops_cdiv(B * kchunks * N, 256 >> gshift), 256 * 64);
+#define LAUNCH_ROWS(M)                                                                                                  \
+    hipLaunchKernelGGL((seg_composite_rows_kernel<T, M>), dim3(rgrid), dim3(256), 0, stream, (const T*)src, rowptr, perm,  \
+                       (T*)out, B, E, K, N, gshift, kchunks, param)
+        switch (mode) {
+            case MODE_SOFTMAX: LAUNCH_ROWS(MODE_SOFTMAX); break;
+            case MODE_LOG_SOFTMAX: LAUNCH_ROWS(MODE_LOG_SOFTMAX); break;
+            case MODE_LOGSUMEXP: LAUNCH_ROWS(MODE_LOGSUMEXP); break;
+            case MODE_STD: LAUNCH_ROWS(MODE_STD); break;
+            default: gnnops_set_error("segment_composite: unknown mode %d", mode); return GNNOPS_EINVAL;
+        }
+#undef LAUNCH_ROWS
+        return gnnops_check_launch("segment_composite");
+    }
     const int grid = gnnops_grid_cap(gnnops_cdiv(B * N * K, 256), 256 * 32);
 #define LAUNCH(M)                                                                                              \
     hipLaunchKernelGGL((seg_composite_kernel<T, M>), dim3(grid), dim3(256), 0, stream, (const T*)src, rowptr, perm, \
