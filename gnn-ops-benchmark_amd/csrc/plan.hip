@@ -35,24 +35,42 @@ __global__ void index_max_kernel(const int64_t* __restrict__ index, int64_t E, i
 // that a skewed index (all edges on one node) does not serialise on one lane.
 constexpr int GAP_INLINE = 32;
 
+// One boundary i in [0, E]: destinations in (key[i-1], key[i]] start at sorted position i.
+__device__ inline void rowptr_boundary(int64_t i, int64_t prev, int64_t cur, int64_t N, int32_t* __restrict__ rowptr,
+                                       int32_t* __restrict__ gap_list, unsigned int* __restrict__ gap_count) {
+    if (cur > N) cur = N;  // out-of-range keys cannot push writes past rowptr[N]
+    const int64_t gap = cur - prev;
+    if (gap <= 0) return;
+    if (gap <= GAP_INLINE) {
+        for (int64_t n = prev + 1; n <= cur; ++n) rowptr[n] = (int32_t)i;
+    } else {
+        const unsigned int slot = atomicAdd(gap_count, 1u);
+        gap_list[3 * (int64_t)slot + 0] = (int32_t)(prev + 1);
+        gap_list[3 * (int64_t)slot + 1] = (int32_t)cur;
+        gap_list[3 * (int64_t)slot + 2] = (int32_t)i;
+    }
+}
+
+// Four boundaries per thread (one 16-B load of u32 keys plus the key before them).
 template <typename KeyT>
 __global__ void rowptr_kernel(const KeyT* __restrict__ sorted_keys, int64_t E, int64_t N,
                               int32_t* __restrict__ rowptr, int32_t* __restrict__ gap_list,
                               unsigned int* __restrict__ gap_count) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= E; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t prev = (i == 0) ? -1 : (int64_t)sorted_keys[i - 1];
-        int64_t cur = (i == E) ? N : (int64_t)sorted_keys[i];
-        if (cur > N) cur = N;  // out-of-range keys cannot push writes past rowptr[N]
-        int64_t gap = cur - prev;
-        if (gap <= 0) continue;
-        if (gap <= GAP_INLINE) {
-            for (int64_t n = prev + 1; n <= cur; ++n) rowptr[n] = (int32_t)i;
+    const int64_t nquads = (E + 1 + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = q * 4;
+        int64_t k[5];  // k[j] = key[i0 - 1 + j]
+        k[0] = (i0 == 0) ? -1 : (int64_t)sorted_keys[i0 - 1];
+        if (sizeof(KeyT) == 4 && i0 + 3 < E && ((uintptr_t)sorted_keys % 16 == 0)) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(sorted_keys + i0);
+            k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
         } else {
-            unsigned int slot = atomicAdd(gap_count, 1u);
-            gap_list[3 * (int64_t)slot + 0] = (int32_t)(prev + 1);
-            gap_list[3 * (int64_t)slot + 1] = (int32_t)cur;
-            gap_list[3 * (int64_t)slot + 2] = (int32_t)i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[1 + j] = (i0 + j < E) ? (int64_t)sorted_keys[i0 + j] : N;
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j <= E) rowptr_boundary(i0 + j, k[j], (i0 + j == E) ? N : k[1 + j], N, rowptr, gap_list, gap_count);
     }
 }
 
@@ -157,7 +175,7 @@ extern "C" int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N, int
     if (hipMemsetAsync(gap_count, 0, sizeof(unsigned int), stream) != hipSuccess)
         return gnnops_check_launch("plan_build memset gap_count");
     {
-        int grid = gnnops_grid_cap(gnnops_cdiv(E + 1, 256));
+        int grid = gnnops_grid_cap(gnnops_cdiv(E + 4, 1024));
         hipLaunchKernelGGL(rowptr_kernel<uint32_t>, dim3(grid), dim3(256), 0, stream, sorted_keys, E, N, rowptr, gap_list, gap_count);
         hipLaunchKernelGGL(fill_gaps_kernel, dim3(512), dim3(256), 0, stream, rowptr, gap_list, gap_count);
     }
@@ -182,7 +200,7 @@ extern "C" int gnnops_rowptr_from_sorted(const int64_t* sorted_index, int64_t E,
     int32_t* gap_list = (int32_t*)((char*)workspace + 256);
     if (hipMemsetAsync(gap_count, 0, sizeof(unsigned int), stream) != hipSuccess)
         return gnnops_check_launch("rowptr_from_sorted memset");
-    const int grid = gnnops_grid_cap(gnnops_cdiv(E + 1, 256));
+    const int grid = gnnops_grid_cap(gnnops_cdiv(E + 4, 1024));
     hipLaunchKernelGGL(rowptr_kernel<int64_t>, dim3(grid), dim3(256), 0, stream, sorted_index, E, N, rowptr, gap_list, gap_count);
     hipLaunchKernelGGL(fill_gaps_kernel, dim3(512), dim3(256), 0, stream, rowptr, gap_list, gap_count);
     return gnnops_check_launch("rowptr_from_sorted");
