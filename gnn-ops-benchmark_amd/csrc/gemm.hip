@@ -17,6 +17,7 @@
 // 8 elements (the reference sweeps L = 1581 ... 8164) are first copied into 16-B aligned, zero-padded rows
 // (pad_rows_kernel, workspace), so the staging loads are always 16-B vectors.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -231,6 +232,116 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint16_t* __restrict
 
 // Copy a [rows][cols] 16-bit matrix into rows of `ld` elements (ld % 8 == 0), zero-filling the tail, so that every
 // row starts 16-B aligned and the GEMM's 16-B staging loads apply (the reference sweeps odd sizes: L = 1581...).
+// Fast path for tile-aligned problems (M % 128 == 0, N % 128 == 0, K % 64 == 0): the same tiles, swizzled images,
+// fragment reads and epilogue, but the staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction written
+// straight into LDS, the swizzle applied on the per-lane SOURCE address), so no staging VGPRs and no ds_write pass.
+// The DMA of tile t+1 is issued before the 32 MFMAs of tile t and retired by the barrier that ends the step.
+template <typename T, bool IS_BF16>
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
+                                                          const T* __restrict__ addend, T* __restrict__ C, int64_t M,
+                                                          int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    constexpr int EPI_BYTES = 4 * 64 * CS * 4;
+    constexpr int SMEM_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // DMA pieces of this wave: A pieces wave*4 .. +3 (8 rows x 128 B each), B pieces wave*4 .. +3 (4 rows x 256 B each).
+    // Lane i lands at byte 16*i of the piece, i.e. (row, position c'); it must fetch global chunk c = c' ^ swizzle(row).
+    const uint16_t* a_src[4];
+    const uint16_t* b_src[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int ar = (wave * 4 + p) * 8 + (lane >> 3);
+        a_src[p] = A + (m0 + ar) * lda + (((lane & 7) ^ (ar & 7)) << 3);
+        const int br = (wave * 4 + p) * 4 + (lane >> 4);
+        b_src[p] = Bm + (int64_t)br * ldb + n0 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
+    }
+    auto dma = [&](int stage, int64_t k0) {
+        unsigned char* base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + (wave * 4 + p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
+                                             (__attribute__((address_space(3))) void*)(base + A_TILE_BYTES + (wave * 4 + p) * 1024),
+                                             16, 0, 0);
+        }
+    };
+
+    const int a_row = wr * 64 + (lane & 15);
+    const int a_kc = lane >> 4;
+    const int b_q = (lane & 15) >> 2, b_p = lane & 3;
+    const int b_row = 8 * (lane >> 4) + b_q;
+
+    const int64_t ksteps = K / BK;
+    dma(0, 0);
+    __syncthreads();
+    for (int64_t kt = 0; kt < ksteps; ++kt) {
+        const int cur = (int)(kt & 1);
+        if (kt + 1 < ksteps) dma(cur ^ 1, (kt + 1) * BK);
+        const unsigned char* sA = smem + cur * STAGE_BYTES;
+        const unsigned char* sB = sA + A_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            s16x8 af[4], bf[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                af[mi] = *reinterpret_cast<const s16x8*>(sA + a_off(a_row + mi * 16, ks * 4 + a_kc));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int ch = wc * 8 + ni * 2 + (b_p >> 1);
+                const int r_lo = ks * 32 + b_row;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sB + b_off(r_lo, ch) + 8 * (b_p & 1)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sB + b_off(r_lo + 4, ch) + 8 * (b_p & 1)));
+                bf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
+        }
+        __syncthreads();  // retires this wave's DMA (vmcnt(0)) and everybody's reads of `cur`
+    }
+
+    float* ctile = reinterpret_cast<float*>(smem) + wave * (64 * CS);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ctile[(mi * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+    __builtin_amdgcn_wave_barrier();
+    const int pr = lane >> 3, pc = (lane & 7) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int rr = pass * 8 + pr;
+        const int64_t o = (m0 + wr * 64 + rr) * N + n0 + wc * 64 + pc;
+        float f[8];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        if (addend) {
+            float g[8];
+            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + o), g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] += g[i];
+        }
+        *reinterpret_cast<u32x4*>(C + o) = Elem<T>::pack(f);
+    }
+}
+
 template <int ALIGN>
 __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                 int64_t ld) {
@@ -305,6 +416,18 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
     GNNOPS_REQUIRE(K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0), GNNOPS_EUNSUPPORTED,
                    "addmm: operand base pointers must be 16-byte aligned");
     dim3 grid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
+    const bool tile_aligned = M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0 && (uintptr_t)out % 16 == 0 &&
+                              (input == nullptr || (uintptr_t)input % 16 == 0);
+    const char* no_dma = getenv("GNNOPS_GEMM_NO_DMA");  // A/B switch for tools/time_gemm.py
+    if (tile_aligned && !(no_dma && no_dma[0] == '1')) {
+        if (dtype == GNNOPS_BF16)
+            hipLaunchKernelGGL((gemm_dma_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
+                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb);
+        else
+            hipLaunchKernelGGL((gemm_dma_kernel<__half, false>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
+                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb);
+        return gnnops_check_launch("addmm");
+    }
     if (dtype == GNNOPS_BF16)
         hipLaunchKernelGGL((gemm_kernel<__hip_bfloat16, true, 16>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
                            (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb);

@@ -51,11 +51,12 @@ def test_addmm_matmul(gnnops, oracle, M, N, K, dname):
 
 def test_addmm_identity_layout(gnnops):
     """A = I with an asymmetric B: catches fragment-layout and transposed-read mistakes exactly."""
-    n = 192
-    B = (torch.arange(n * n).view(n, n) % 251).to(torch.bfloat16)  # integers < 256 are exact in bf16
-    I = torch.eye(n, dtype=torch.bfloat16)
-    assert torch.equal(gnnops.matmul(I.cuda(), B.cuda()).cpu(), B)
-    assert torch.equal(gnnops.matmul(B.cuda(), I.cuda()).cpu(), B)
+    for n in (192, 256, 384):  # 192: register-staged kernel; 256 / 384: tile-aligned -> LDS-DMA kernel
+        B = (torch.arange(n * n).view(n, n) % 251).to(torch.bfloat16)  # integers < 256 are exact in bf16
+        I = torch.eye(n, dtype=torch.bfloat16)
+        assert torch.equal(gnnops.matmul(I.cuda(), B.cuda()).cpu(), B), n
+        assert torch.equal(gnnops.matmul(B.cuda(), I.cuda()).cpu(), B), n
+        assert torch.equal(gnnops.addmm(B.cuda(), I.cuda(), B.cuda()).cpu(), (B.float() * 2).to(torch.bfloat16)), n
 
 
 def test_addmm_reference_shape_fp16(gnnops):

@@ -6,7 +6,10 @@ import torch
 import gnnops
 sizes = [int(a) for a in sys.argv[1:]] or [4096, 8164, 8192]
 for dt in (torch.bfloat16, torch.float16):
-    for L in sizes:
+  for L in sizes:
+   for no_dma in ("0", "1", "0", "1"):
+    os.environ["GNNOPS_GEMM_NO_DMA"] = no_dma
+    if True:
         g = torch.Generator(device="cuda").manual_seed(1)
         a = (torch.rand(L, L, generator=g, device="cuda") * 2 - 1).to(dt)
         b = (torch.rand(L, L, generator=g, device="cuda") * 2 - 1).to(dt)
@@ -23,4 +26,4 @@ for dt in (torch.bfloat16, torch.float16):
         ms = s.elapsed_time(e) / n
         ref = torch.addmm(c, a, b)
         err = (out.float() - ref.float()).abs().max().item()
-        print(f"{str(dt):16s} L={L:6d} {ms:8.3f} ms  {2*L**3/ms/1e9:8.1f} TFLOP/s  maxdiff_vs_torch={err:.4f}", flush=True)
+        print(f"{str(dt):16s} no_dma={no_dma} L={L:6d} {ms:8.3f} ms  {2*L**3/ms/1e9:8.1f} TFLOP/s  maxdiff_vs_torch={err:.4f}", flush=True)
