@@ -281,7 +281,8 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
                                    int64_t K, int64_t E, int elem_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "index_select: negative size");
-    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "index_select: elem_bytes %d", elem_bytes);
+    GNNOPS_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, GNNOPS_EUNSUPPORTED,
+                   "index_select: elem_bytes %d", elem_bytes);
     if (B * E * K == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(input && index && out, GNNOPS_EINVAL, "index_select: null pointer");
     const int64_t rowbytes = K * elem_bytes;
@@ -296,9 +297,14 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
     } else {
         // a row index with K > 1 is already coalesced along k in the element kernel; LDS staging pays for K == 1 rows
         if (const int tc = gather_lds_width(N, K, E, elem_bytes);
-            tc > 0 && K * elem_bytes <= 8 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31))
-            return elem_bytes == 4 ? launch_gather_lds<uint32_t, false>(input, index, out, B, N, K, E, tc, stream)
-                                   : launch_gather_lds<uint16_t, false>(input, index, out, B, N, K, E, tc, stream);
+            tc > 0 && K * elem_bytes <= 8 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31)) {
+            switch (elem_bytes) {
+                case 1: return launch_gather_lds<uint8_t, false>(input, index, out, B, N, K, E, tc, stream);
+                case 2: return launch_gather_lds<uint16_t, false>(input, index, out, B, N, K, E, tc, stream);
+                case 4: return launch_gather_lds<uint32_t, false>(input, index, out, B, N, K, E, tc, stream);
+                default: return launch_gather_lds<uint64_t, false>(input, index, out, B, N, K, E, tc, stream);
+            }
+        }
         // copy in the widest unit that divides the row and the base alignment (a row is one opaque byte string)
         const uintptr_t al = (uintptr_t)input | (uintptr_t)out | (uintptr_t)rowbytes;
         int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
@@ -308,9 +314,12 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
         else if (al % 4 == 0)
             hipLaunchKernelGGL((select_elems_kernel<uint32_t, false>), dim3(grid), dim3(256), 0, stream,
                                (const uint32_t*)input, index, (uint32_t*)out, B, N, rowbytes / 4, E);
-        else
+        else if (al % 2 == 0)
             hipLaunchKernelGGL((select_elems_kernel<uint16_t, false>), dim3(grid), dim3(256), 0, stream,
                                (const uint16_t*)input, index, (uint16_t*)out, B, N, rowbytes / 2, E);
+        else
+            hipLaunchKernelGGL((select_elems_kernel<uint8_t, false>), dim3(grid), dim3(256), 0, stream,
+                               (const uint8_t*)input, index, (uint8_t*)out, B, N, rowbytes, E);
     }
     return gnnops_check_launch("index_select");
 }
@@ -320,8 +329,8 @@ extern "C" int gnnops_index_select_planned(const void* input, const int32_t* row
                                            gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "index_select_planned: negative size");
-    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "index_select_planned: elem_bytes %d",
-                   elem_bytes);
+    GNNOPS_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, GNNOPS_EUNSUPPORTED,
+                   "index_select_planned: elem_bytes %d", elem_bytes);
     if (B * E * K == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(input && rowptr && perm && out, GNNOPS_EINVAL, "index_select_planned: null pointer");
     const int64_t rowbytes = K * elem_bytes;
@@ -339,19 +348,25 @@ extern "C" int gnnops_gather(const void* input, const int64_t* index, void* out,
                              int64_t E, int elem_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "gather: negative size");
-    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "gather: elem_bytes %d", elem_bytes);
+    GNNOPS_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, GNNOPS_EUNSUPPORTED,
+                   "gather: elem_bytes %d", elem_bytes);
     if (B * E * K == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(input && index && out, GNNOPS_EINVAL, "gather: null pointer");
-    if (const int tc = gather_lds_width(N, K, E, elem_bytes); tc > 0 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31))
-        return elem_bytes == 4 ? launch_gather_lds<uint32_t, true>(input, index, out, B, N, K, E, tc, stream)
-                               : launch_gather_lds<uint16_t, true>(input, index, out, B, N, K, E, tc, stream);
-    int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
-    if (elem_bytes == 4)
-        hipLaunchKernelGGL((select_elems_kernel<uint32_t, true>), dim3(grid), dim3(256), 0, stream,
-                           (const uint32_t*)input, index, (uint32_t*)out, B, N, K, E);
-    else
-        hipLaunchKernelGGL((select_elems_kernel<uint16_t, true>), dim3(grid), dim3(256), 0, stream,
-                           (const uint16_t*)input, index, (uint16_t*)out, B, N, K, E);
+    const int tc = gather_lds_width(N, K, E, elem_bytes);
+    const bool lds = tc > 0 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31);
+    const int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
+#define GATHER_CASE(U)                                                                                              \
+    if (lds) return launch_gather_lds<U, true>(input, index, out, B, N, K, E, tc, stream);                          \
+    hipLaunchKernelGGL((select_elems_kernel<U, true>), dim3(grid), dim3(256), 0, stream, (const U*)input, index,     \
+                       (U*)out, B, N, K, E);                                                                         \
+    break
+    switch (elem_bytes) {
+        case 1: GATHER_CASE(uint8_t);
+        case 2: GATHER_CASE(uint16_t);
+        case 4: GATHER_CASE(uint32_t);
+        default: GATHER_CASE(uint64_t);
+    }
+#undef GATHER_CASE
     return gnnops_check_launch("gather");
 }
 

@@ -104,7 +104,7 @@ __global__ void reduce_runs_kernel(const T* __restrict__ value, const uint32_t* 
 template <typename U>
 __global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in, U* __restrict__ out, int64_t R,
                                                         int64_t C) {
-    __shared__ U tile[64][64 + (4 / sizeof(U) > 0 ? 4 / sizeof(U) : 1)];
+    __shared__ U tile[64][64 + (sizeof(U) >= 4 ? 1 : 4 / sizeof(U))];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
 #pragma unroll
@@ -216,14 +216,19 @@ extern "C" int gnnops_coalesce(const int64_t* row, const int64_t* col, const voi
 extern "C" int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(R >= 0 && C >= 0, GNNOPS_EINVAL, "transpose2d: negative size");
-    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, GNNOPS_EUNSUPPORTED, "transpose2d: elem_bytes %d", elem_bytes);
+    GNNOPS_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, GNNOPS_EUNSUPPORTED,
+                   "transpose2d: elem_bytes %d", elem_bytes);
     if (R * C == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(in && out, GNNOPS_EINVAL, "transpose2d: null pointer");
     GNNOPS_REQUIRE(gnnops_cdiv(R, 64) < 65536, GNNOPS_EUNSUPPORTED, "transpose2d: too many rows");
     dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64));
-    if (elem_bytes == 2)
+    if (elem_bytes == 1)
+        hipLaunchKernelGGL((transpose_kernel<uint8_t>), grid, dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, R, C);
+    else if (elem_bytes == 2)
         hipLaunchKernelGGL((transpose_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, R, C);
-    else
+    else if (elem_bytes == 4)
         hipLaunchKernelGGL((transpose_kernel<uint32_t>), grid, dim3(256), 0, stream, (const uint32_t*)in, (uint32_t*)out, R, C);
+    else
+        hipLaunchKernelGGL((transpose_kernel<uint64_t>), grid, dim3(256), 0, stream, (const uint64_t*)in, (uint64_t*)out, R, C);
     return gnnops_check_launch("transpose2d");
 }

@@ -305,8 +305,8 @@ def _inplace_scatter(self, dim, index, src, reduce, what):
 # --------------------------------------------------------------------------------------------------
 def _elem_bytes(t, what):
     eb = t.element_size()
-    if eb not in (2, 4):
-        raise NotImplementedError(f"gnnops.{what}: element size {eb} is not supported (2- or 4-byte types)")
+    if eb not in (1, 2, 4, 8) or t.is_complex():
+        raise NotImplementedError(f"gnnops.{what}: element size {eb} is not supported (1/2/4/8-byte real types)")
     return eb
 
 

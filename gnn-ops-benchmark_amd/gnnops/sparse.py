@@ -161,7 +161,7 @@ def transpose_contiguous(mat):
     if mat.dim() != 2:
         raise NotImplementedError("gnnops.transpose_contiguous: 2-D tensors only")
     eb = mat.element_size()
-    if eb not in (2, 4):
+    if eb not in (1, 2, 4, 8):
         raise NotImplementedError(f"gnnops.transpose_contiguous: element size {eb}")
     mat = mat.contiguous()
     R, C = mat.shape

@@ -109,7 +109,7 @@ int gnnops_scatter_elementwise(const void* src, const int64_t* index, void* out,
 /* ---------------------------------------------------------------------------------------------
  * torch.index_select (benchmark_native_index_select.py:12-15; also the first half of
  * benchmark_fused_index_select_reduce.py:12-20).  input [B,N,K], index int64 [E] -> out [B,E,K],
- * out[b,e,k] = input[b,index[e],k].  Bit-exact copy; `elem_bytes` in {2,4}.
+ * out[b,e,k] = input[b,index[e],k].  Bit-exact copy of opaque elements; `elem_bytes` in {1,2,4,8}.
  * ------------------------------------------------------------------------------------------- */
 int gnnops_index_select(const void* input, const int64_t* index, void* out,
                         int64_t B, int64_t N, int64_t K, int64_t E,
@@ -176,7 +176,7 @@ int gnnops_coalesce(const int64_t* row, const int64_t* col, const void* value, i
                     void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 
 /* Dense 2-D transpose copy: torch.transpose(matA, 0, 1).contiguous() (benchmark_sparse_transpose.py:13-16).
- * in [R, C] -> out [C, R]; elem_bytes in {2, 4}; bit-exact. */
+ * in [R, C] -> out [C, R]; elem_bytes in {1, 2, 4, 8}; bit-exact. */
 int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes,
                        gnnops_stream_t stream);
 

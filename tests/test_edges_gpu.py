@@ -101,7 +101,7 @@ def test_c_abi_argument_checks(gnnops):
     assert L.gnnops_plan_build(idx.data_ptr(), 1 << 31, 2, buf.data_ptr(), buf.data_ptr(), None, 0, None) == 4  # E >= 2^31
     assert L.gnnops_segment_reduce(None, buf.data_ptr(), None, buf.data_ptr(), None, 1, 0, 4, 2, 9, 0, 0, None) == 1  # dtype 9
     assert L.gnnops_segment_reduce(None, buf.data_ptr(), None, buf.data_ptr(), None, 1, 0, 4, 2, 0, 1, 1, None) == 1  # mean + init
-    assert L.gnnops_index_select(buf.data_ptr(), idx.data_ptr(), buf.data_ptr(), 1, 4, 4, 4, 8, None) == 4      # 8-byte elems
+    assert L.gnnops_index_select(buf.data_ptr(), idx.data_ptr(), buf.data_ptr(), 1, 4, 4, 4, 3, None) == 4      # 3-byte elems
     assert L.gnnops_addmm(None, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 2, 2, 2, 0, None, 0, None) == 4  # fp32 GEMM
     torch.cuda.synchronize()
 
@@ -138,3 +138,25 @@ def test_skewed_and_maximal_degree(gnnops, oracle):
     got = gnnops.scatter_add(few.cuda(), far.cuda(), 0)              # dim_size discovered: 3,000,000 rows, 6 non-empty
     assert got.shape == (3_000_000, 16)
     assert_bits_equal(got.cpu().numpy(), oracle.scatter(few.numpy(), far.numpy(), 0), "sparse destinations")
+
+
+def test_byte_movers_take_any_real_dtype(gnnops):
+    """index_select / gather / transpose are opaque byte movers: int64, int32, uint8, bool, float64 all work
+    (so torch.index_select on an edge_index keeps working after gnnops.install())."""
+    g = torch.Generator().manual_seed(6)
+    for dt in (torch.int64, torch.int32, torch.uint8, torch.bool, torch.float64, torch.int16):
+        x = (torch.rand(300, 37, generator=g) * 200).to(dt)
+        idx = torch.randint(0, 300, (500,), generator=g)
+        assert torch.equal(gnnops.index_select(x.cuda(), 0, idx.cuda()).cpu(), x[idx]), dt
+        cidx = torch.randint(0, 37, (20,), generator=g)
+        assert torch.equal(gnnops.index_select(x.cuda(), 1, cidx.cuda()).cpu(), x[:, cidx]), dt
+        gi = torch.randint(0, 300, (150, 37), generator=g)
+        assert torch.equal(gnnops.gather(x.cuda(), 0, gi.cuda()).cpu(), torch.gather(x, 0, gi)), dt
+        assert torch.equal(gnnops.transpose_contiguous(x.cuda()).cpu(), x.t().contiguous()), dt
+    gnnops.install()
+    try:
+        ei = torch.randint(0, 50, (2, 400), generator=g).cuda()
+        perm = torch.randperm(400, generator=g).cuda()
+        assert torch.equal(torch.index_select(ei, 1, perm), ei[:, perm])
+    finally:
+        gnnops.uninstall()
