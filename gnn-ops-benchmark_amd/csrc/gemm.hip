@@ -342,6 +342,122 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const uint16_t* __rest
     }
 }
 
+// ---- fp32 operands: v_mfma_f32_16x16x4_f32 (exact fp32 products and sums, 1/16 of the bf16 MFMA rate = the fp32
+// vector peak, MI355X_MICROARCH.md "Matrix cores"). Same 128 x 128 block / 2 x 2 waves / 4 x 4 MFMA tiles; BK = 16.
+// A tile [128][16] with 20-float rows and B tile [16][128] with 144-float rows: both fragment reads (one ds_read_b32
+// per lane: A[row l&15][k l>>4], B[k l>>4][col l&15]) are bank-conflict-free, and B needs no transpose at all.
+constexpr int FBK = 16, FAS = 20, FBS = 144;
+
+__device__ inline f32x4 load4f(const float* __restrict__ base, int64_t r, int64_t c, int64_t rows, int64_t cols, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r >= rows || c >= cols) return v;
+    const float* p = base + r * cols + c;
+    if (vec && c + 4 <= cols) return *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (c + i < cols) v[i] = p[i];
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                          const float* __restrict__ addend, float* __restrict__ C,
+                                                          int64_t M, int64_t N, int64_t K, bool a_vec, bool b_vec) {
+    constexpr int STAGE_F = BM * FAS + FBK * FBS;       // floats per stage (2560 + 2304)
+    constexpr int EPI_F = 4 * 64 * CS;
+    constexpr int SMEM_F = (2 * STAGE_F > EPI_F) ? 2 * STAGE_F : EPI_F;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: A 128 x 16 floats = 512 float4 chunks (2 per thread), B 16 x 128 = 512 chunks (2 per thread)
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int64_t k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int id = tid + 256 * p;
+            ra[p] = load4f(A, m0 + (id >> 2), k0 + (id & 3) * 4, M, K, a_vec);
+            rb[p] = load4f(Bm, k0 + (id >> 5), n0 + (id & 31) * 4, K, N, b_vec);
+        }
+    };
+    auto sstore = [&](int stage) {
+        float* sA = smem + stage * STAGE_F;
+        float* sB = sA + BM * FAS;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int id = tid + 256 * p;
+            *reinterpret_cast<f32x4*>(&sA[(id >> 2) * FAS + (id & 3) * 4]) = ra[p];
+            *reinterpret_cast<f32x4*>(&sB[(id >> 5) * FBS + (id & 31) * 4]) = rb[p];
+        }
+    };
+
+    const int64_t ksteps = (K + FBK - 1) / FBK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int64_t kt = 0; kt < ksteps; ++kt) {
+        const int cur = (int)(kt & 1);
+        const bool more = kt + 1 < ksteps;
+        if (more) gload((kt + 1) * FBK);
+        const float* sA = smem + cur * STAGE_F;
+        const float* sB = sA + BM * FAS;
+#pragma unroll
+        for (int ks = 0; ks < FBK / 4; ++ks) {
+            float af[4], bf[4];
+            const int kk = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = sA[(wr * 64 + mi * 16 + (lane & 15)) * FAS + kk];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bf[ni] = sB[kk * FBS + wc * 64 + ni * 16 + (lane & 15)];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* ctile = smem + wave * (64 * CS);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ctile[(mi * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+    __builtin_amdgcn_wave_barrier();
+    const bool vec_c = (N % 4 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
+    const int pr = lane >> 4, pc = (lane & 15) * 4;  // 16 lanes x 4 columns per row, 4 rows per pass
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+        const int rr = pass * 4 + pr;
+        const int64_t row = m0 + wr * 64 + rr;
+        const int64_t col = n0 + wc * 64 + pc;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
+        if (row >= M || col >= N) continue;
+        if (vec_c && col + 4 <= N) {
+            if (addend) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * N + col);
+                v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];
+            }
+            *reinterpret_cast<f32x4*>(C + row * N + col) = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * N + col + i] : 0.f);
+        }
+    }
+}
+
 template <int ALIGN>
 __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                 int64_t ld) {
@@ -383,7 +499,7 @@ inline int64_t round8(int64_t v) { return (v + 7) / 8 * 8; }
 extern "C" size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M < 0 || N < 0 || K < 0) return 0;
     size_t b = 0;
-    if (K % 8) b += align_up((size_t)M * round8(K) * 2, 256);
+    if (K % 8) b += align_up((size_t)M * round8(K) * 2, 256);   // 16-bit operands only; fp32 needs none
     if (N % 8) b += align_up((size_t)K * round8(N) * 2, 256);
     return b;
 }
@@ -392,11 +508,19 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
                             int64_t K, int dtype, void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(M >= 0 && N >= 0 && K >= 0, GNNOPS_EINVAL, "addmm: negative size");
-    GNNOPS_REQUIRE(dtype == GNNOPS_F16 || dtype == GNNOPS_BF16, GNNOPS_EUNSUPPORTED,
-                   "addmm: only float16 / bfloat16 operands are supported (dtype code %d)", dtype);
+    GNNOPS_REQUIRE(dtype == GNNOPS_F16 || dtype == GNNOPS_BF16 || dtype == GNNOPS_F32, GNNOPS_EUNSUPPORTED,
+                   "addmm: unknown dtype code %d", dtype);
     if (M * N == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(out && (K == 0 || (mat1 && mat2)), GNNOPS_EINVAL, "addmm: null pointer");
     GNNOPS_REQUIRE(gnnops_cdiv(M, BM) < 65536, GNNOPS_EUNSUPPORTED, "addmm: M too large for the grid");
+    if (dtype == GNNOPS_F32) {
+        const bool a_vec = (K % 4 == 0) && ((uintptr_t)mat1 % 16 == 0);
+        const bool b_vec = (N % 4 == 0) && ((uintptr_t)mat2 % 16 == 0);
+        dim3 fgrid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
+        hipLaunchKernelGGL(gemm_f32_kernel, fgrid, dim3(256), 0, stream, (const float*)mat1, (const float*)mat2,
+                           (const float*)input, (float*)out, M, N, K, a_vec, b_vec);
+        return gnnops_check_launch("addmm f32");
+    }
     const size_t need = gnnops_addmm_workspace_bytes(M, N, K);
     GNNOPS_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), GNNOPS_EWORKSPACE, "addmm: workspace %zu < %zu",
                    workspace_bytes, need);

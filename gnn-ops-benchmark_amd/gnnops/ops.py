@@ -456,7 +456,8 @@ def index_add_select_sum(input, dim, index, other):
 
 
 def addmm(input, mat1, mat2, *, beta=1, alpha=1):
-    """torch.addmm(input, mat1, mat2) for float16 / bfloat16 matrices (benchmark_native_addmm.py:13-16)."""
+    """torch.addmm(input, mat1, mat2) for float16 / bfloat16 / float32 matrices (benchmark_native_addmm.py:13-16;
+    fp32 is the dtype of the older data/native_addmm.csv sweep)."""
     if beta != 1 or alpha != 1:
         raise NotImplementedError("gnnops.addmm: beta and alpha must be 1")
     _require_gpu(input, mat1, mat2)
@@ -467,8 +468,8 @@ def addmm(input, mat1, mat2, *, beta=1, alpha=1):
                            f"{mat2.size(0)}x{mat2.size(1)})")
     if mat1.dtype != mat2.dtype or (input is not None and input.dtype != mat1.dtype):
         raise RuntimeError("addmm: operands must have the same dtype")
-    if mat1.dtype not in (torch.float16, torch.bfloat16):
-        raise NotImplementedError(f"gnnops.addmm: dtype {mat1.dtype} is not supported (float16/bfloat16)")
+    if mat1.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        raise NotImplementedError(f"gnnops.addmm: dtype {mat1.dtype} is not supported (float16/bfloat16/float32)")
     dt = _DT[mat1.dtype]
     M, K = mat1.shape
     N = mat2.size(1)

@@ -183,7 +183,8 @@ int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem
 /* ---------------------------------------------------------------------------------------------
  * torch.addmm(input, mat1, mat2) / torch.matmul(input, other) on 16-bit operands
  * (benchmark_native_addmm.py:13-16, benchmark_native_matmul.py:13-16): out[M,N] = input[M,N] + mat1[M,K] @
- * mat2[K,N] (input == NULL: plain matmul). Row-major, dtype F16 or BF16, fp32 MFMA accumulation, one rounding.
+ * mat2[K,N] (input == NULL: plain matmul). Row-major; dtype F16 / BF16 (fp32 MFMA accumulation, one rounding) or
+ * F32 (exact-fp32 MFMA).
  * ------------------------------------------------------------------------------------------- */
 size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* 0 when K % 8 == 0 and N % 8 == 0 */
 int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out,

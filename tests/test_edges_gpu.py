@@ -102,7 +102,7 @@ def test_c_abi_argument_checks(gnnops):
     assert L.gnnops_segment_reduce(None, buf.data_ptr(), None, buf.data_ptr(), None, 1, 0, 4, 2, 9, 0, 0, None) == 1  # dtype 9
     assert L.gnnops_segment_reduce(None, buf.data_ptr(), None, buf.data_ptr(), None, 1, 0, 4, 2, 0, 1, 1, None) == 1  # mean + init
     assert L.gnnops_index_select(buf.data_ptr(), idx.data_ptr(), buf.data_ptr(), 1, 4, 4, 4, 3, None) == 4      # 3-byte elems
-    assert L.gnnops_addmm(None, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 2, 2, 2, 0, None, 0, None) == 4  # fp32 GEMM
+    assert L.gnnops_addmm(None, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 2, 2, 2, 7, None, 0, None) == 4  # dtype 7
     torch.cuda.synchronize()
 
 

@@ -105,3 +105,21 @@ def test_aten_sort_and_addmm_overrides(gnnops):
     ref = C.double() + A.double() @ B.double()
     assert ((out.double().cpu() - ref).abs() / ref.abs()).max() <= 2.0 ** -10
     assert ((mm.double().cpu() - A.double() @ B.double()).abs().max()) <= 2.0 ** -10 * 64
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 512), (130, 70, 100), (1, 1, 1), (17, 9, 40), (333, 257, 191)])
+def test_addmm_fp32(gnnops, M, N, K):
+    """fp32 operands run on v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 sums in k order.
+    Tolerance: |err| <= 2 * K * 2^-24 * (|A| @ |B| + |C|) against a float64 reference."""
+    g = torch.Generator().manual_seed(33)
+    A = torch.rand(M, K, generator=g) * 2 - 1
+    B = torch.rand(K, N, generator=g) * 2 - 1 + torch.arange(N).float().view(1, N) / max(N, 1)
+    C = torch.rand(M, N, generator=g) * 2 - 1
+    got = gnnops.addmm(C.cuda(), A.cuda(), B.cuda()).cpu().double()
+    ref = C.double() + A.double() @ B.double()
+    bound = 2 * max(K, 1) * 2.0 ** -24 * (A.double().abs() @ B.double().abs() + C.double().abs()) + 1e-30
+    assert ((got - ref).abs() <= bound).all(), ((got - ref).abs() / bound).max()
+    n = 160
+    Bi = (torch.arange(n * n).view(n, n) % 1009).float()
+    assert torch.equal(gnnops.matmul(torch.eye(n).cuda(), Bi.cuda()).cpu(), Bi)
+    assert torch.equal(gnnops.matmul(Bi.cuda(), torch.eye(n).cuda()).cpu(), Bi)
