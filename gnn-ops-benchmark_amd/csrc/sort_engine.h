@@ -16,6 +16,8 @@ int pass_first_i64(const int64_t* index, uint32_t* keys_out, uint32_t* vals_out,
                    uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream);
 int pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
              int shift, uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream);
+int pass_first_u32(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n, int shift,
+                   uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream);
 int pass_first_f32(const float* keys_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n, int shift,
                    uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream);
 int pass_first_u64(const uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n, int shift,

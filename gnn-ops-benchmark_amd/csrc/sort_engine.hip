@@ -15,6 +15,12 @@ int pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ou
                                          num_tiles, stream);
 }
 
+int pass_first_u32(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n, int shift,
+                   uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream) {
+    return run_pass<KeyU32, true, true>(keys_in, nullptr, keys_out, vals_out, n, shift, tile_hist, digit_total, num_tiles,
+                                        stream);
+}
+
 int pass_first_f32(const float* keys_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n, int shift,
                    uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream) {
     return run_pass<KeyF32, true, true>(keys_in, nullptr, keys_out, vals_out, n, shift, tile_hist, digit_total,

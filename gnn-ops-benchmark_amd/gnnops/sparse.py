@@ -172,25 +172,30 @@ def transpose_contiguous(mat):
     return out
 
 
+_SORT_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.int32: 3, torch.int64: 4, torch.float64: 5}
+
+
 def sort(input, dim=-1, descending=False, stable=False):
-    """torch.sort(input, dim, stable=...) for float32: (values, indices int64), ascending, always stable."""
+    """torch.sort(input, dim, descending, stable): (values, indices int64), always stable.
+    float32 / float16 / bfloat16 / int32 along any dim; int64 / float64 for 1-D tensors."""
     _require_gpu(input)
-    if descending:
-        raise NotImplementedError("gnnops.sort: descending=True is not supported")
-    if input.dtype != torch.float32:
-        raise NotImplementedError(f"gnnops.sort: dtype {input.dtype} is not supported (float32)")
+    if input.dtype not in _SORT_DT:
+        raise NotImplementedError(f"gnnops.sort: dtype {input.dtype} is not supported")
     if input.dim() == 0:
         return input.clone(), torch.zeros((), dtype=torch.int64, device=input.device)
     dim = _norm_dim(dim, input.dim(), "sort")
     input = input.contiguous()
     B, E, K = _bek(input.shape, dim)
+    sd = _SORT_DT[input.dtype]
+    if sd >= 4 and B * K != 1:
+        raise NotImplementedError(f"gnnops.sort: {input.dtype} is sorted for 1-D tensors only")
     values = torch.empty_like(input)
     indices = torch.empty(input.shape, dtype=torch.int64, device=input.device)
     L = _lib.load()
-    ws_bytes = L.gnnops_sort_workspace_bytes(B, E, K)
+    ws_bytes = L.gnnops_sort_workspace_bytes(B, E, K, sd)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=input.device)
     with torch.cuda.device(input.device):
-        rc = L.gnnops_sort_f32(input.data_ptr(), values.data_ptr(), indices.data_ptr(), B, E, K, ws.data_ptr(), ws_bytes,
-                               _stream())
+        rc = L.gnnops_sort(input.data_ptr(), values.data_ptr(), indices.data_ptr(), B, E, K, sd, 1 if descending else 0,
+                           ws.data_ptr(), ws_bytes, _stream())
     check(rc, "sort")
     return values, indices

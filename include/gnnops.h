@@ -154,13 +154,14 @@ int gnnops_spmm(const int32_t* rowptr, const int32_t* perm, const int64_t* col, 
                 gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * torch.sort(input, dim, stable) for fp32 (benchmark_native_sort.py:28-30). input viewed [B,E,K],
- * sorted ascending along E; values fp32 [B,E,K], indices int64 [B,E,K] (position along E). Always
- * stable. -0.0 is ordered (and returned) as +0.0, NaNs last.
+ * torch.sort(input, dim, descending, stable) (benchmark_native_sort.py:28-30 times fp32). input viewed
+ * [B,E,K], sorted along E; values [B,E,K] of the input dtype, indices int64 [B,E,K] (position along E).
+ * Always stable. sort_dtype: 0 f32, 1 f16, 2 bf16, 3 i32, 4 i64, 5 f64 (64-bit types: B*K == 1 only).
+ * -0.0 is ordered (and returned) as +0.0; NaNs last (first when descending).
  * ------------------------------------------------------------------------------------------- */
-size_t gnnops_sort_workspace_bytes(int64_t B, int64_t E, int64_t K);
-int gnnops_sort_f32(const float* input, float* values, int64_t* indices, int64_t B, int64_t E, int64_t K,
-                    void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+size_t gnnops_sort_workspace_bytes(int64_t B, int64_t E, int64_t K, int sort_dtype);
+int gnnops_sort(const void* input, void* values, int64_t* indices, int64_t B, int64_t E, int64_t K,
+                int sort_dtype, int descending, void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch_sparse.coalesce(index, value, m, n, op="add") / Tensor.coalesce()

@@ -81,7 +81,7 @@ def test_python_boundary_errors(gnnops):
     with pytest.raises(RuntimeError, match="cannot be multiplied"):
         gnnops.matmul(src.half(), src.half())
     with pytest.raises(NotImplementedError):
-        gnnops.sort(src, descending=True)
+        gnnops.sort(src.to(torch.int64), dim=0)   # 64-bit keys: 1-D only
     plan = gnnops.Plan(idx, 3)
     with pytest.raises(ValueError, match="N=3"):
         gnnops.get_plan(plan, 4)

@@ -158,3 +158,26 @@ def test_spspmm(gnnops, oracle, m, k, n, nnzA, nnzB, dname):
         got = gnnops.sparse_mm(A.cuda(), Bs.cuda())
         assert got.is_coalesced() and np.array_equal(got.indices().cpu().numpy(), ref.indices().numpy())
         np.testing.assert_allclose(got.values().cpu().numpy(), ref.values().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16, torch.int32, torch.int64, torch.float64])
+@pytest.mark.parametrize("descending", [False, True])
+def test_sort_dtypes_and_descending(gnnops, dt, descending):
+    """Against torch.sort(stable=True) on the CPU (the reference's own op): values and indices bit-exact."""
+    g = torch.Generator().manual_seed(77)
+    shapes = [(70_001,)] if dt in (torch.int64, torch.float64) else [(70_001,), (130, 257), (9, 40, 11)]
+    for shape in shapes:
+        if dt.is_floating_point:
+            x = (torch.randn(shape, generator=g) * 3).to(dt)
+            x = torch.where(torch.rand(shape, generator=g) < 0.3, torch.zeros((), dtype=dt), x)  # ties
+        else:
+            x = torch.randint(-1000, 1000, shape, generator=g).to(dt)
+        for dim in range(len(shape)):
+            ev, ei = torch.sort(x, dim=dim, descending=descending, stable=True)
+            v, i = gnnops.sort(x.cuda(), dim=dim, descending=descending, stable=True)
+            assert torch.equal(i.cpu(), ei), (dt, shape, dim, descending)
+            assert torch.equal(v.cpu(), ev), (dt, shape, dim, descending)
+    big = torch.tensor([2**62, -2**63, 0, -1, 2**63 - 1, 5], dtype=torch.int64)
+    v, i = gnnops.sort(big.cuda(), descending=descending)
+    ev, ei = torch.sort(big, descending=descending, stable=True)
+    assert torch.equal(v.cpu(), ev) and torch.equal(i.cpu(), ei)
