@@ -234,6 +234,33 @@ __global__ __launch_bounds__(256) void select_sum_elems_kernel(const T* __restri
     if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
+// K == 1 (index_select along the last dim of a matrix, then sum): a workgroup walks rows b, parks each row in LDS and
+// sums the selected elements from there (coalesced row read, coalesced index read, LDS gathers).
+template <typename T>
+__global__ __launch_bounds__(1024) void select_sum_lds_kernel(const T* __restrict__ in, const int64_t* __restrict__ index,
+                                                              float* __restrict__ partial, int64_t B, int64_t N, int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ss_raw[];
+    T* row = reinterpret_cast<T*>(ss_raw);
+    __shared__ float s_part[16];
+    float acc = 0.f;
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();  // previous row fully consumed
+        for (int64_t n = threadIdx.x; n < N; n += 1024) row[n] = in[b * N + n];
+        __syncthreads();
+        for (int64_t e = threadIdx.x; e < E; e += 1024) acc += Elem<T>::load(row + index[e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_part[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
 // Fixed-order combine of the block partials (one block), so the result is run-to-run reproducible.
 __global__ __launch_bounds__(256) void combine_partials_kernel(const float* __restrict__ partial, int n,
                                                                float* __restrict__ out) {
@@ -266,6 +293,17 @@ int launch_select_sum(const void* input, const int64_t* index, float* d_sum, int
         grid = gnnops_grid_cap(gnnops_cdiv(items, (256 >> g.gshift) * ROWS_IN_FLIGHT), FUSED_BLOCKS);
         hipLaunchKernelGGL((select_sum_rows_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)input, index,
                            partial, B, N, K, E, g.gshift, g.chunks);
+    } else if (K == 1 && (size_t)N * sizeof(T) <= GL_BUDGET && E * 4 >= N) {
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_sum_lds_kernel<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL_BUDGET) != hipSuccess)
+                return gnnops_check_launch("select_sum_lds attribute");
+            configured = true;
+        }
+        grid = gnnops_grid_cap(B, FUSED_BLOCKS);
+        hipLaunchKernelGGL((select_sum_lds_kernel<T>), dim3(grid), dim3(1024), (size_t)N * sizeof(T), stream, (const T*)input,
+                           index, partial, B, N, E);
     } else {
         grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256 * 4), FUSED_BLOCKS);
         hipLaunchKernelGGL((select_sum_elems_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)input, index,
