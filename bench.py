@@ -140,7 +140,7 @@ def main():
     }
 
     if rank == 0 and world == 1:
-        result["roofline"] = roofline_leg(torch, gnnops, lib, src, index, Ntot, E, D, args.steps)
+        result["roofline"] = roofline_leg(torch, gnnops, lib, src, index, Ntot, E, D, args.steps, args.workload == "c2")
         result["warm"] = warm_leg(torch, gnnops, src, index, Ntot, E, D, args.steps)
         if not args.no_extra_ops:
             result["ops"] = extra_ops(torch, gnnops, src, index, Ntot, E, D)
@@ -174,7 +174,7 @@ def _event_ms(torch, fn, iters):
     return start.elapsed_time(end) / iters
 
 
-def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters):
+def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters, pmc_applies):
     """Dominant kernel: seg_rows_kernel<float, SUM> (one launch of gnnops_segment_reduce over a prebuilt plan)."""
     from gnnops import _lib
     from gnnops.ops import _stream
@@ -193,7 +193,7 @@ def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters):
     achieved = alg / (ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if pmc_applies and os.path.exists(tpath):  # the committed PMC passes were taken at config 2
         try:
             traffic = json.load(open(tpath)).get("seg_rows_kernel_f32_sum", {}).get("hbm_bytes_per_launch")
         except Exception:
