@@ -35,7 +35,7 @@ from .sparse import (coalesce, coalesce_sparse_tensor, sort, sparse_mm, spmm, sp
                      transpose_contiguous)
 from .segment import (gather_coo, gather_csr, rowptr_from_sorted, scatter_log_softmax, scatter_logsumexp, scatter_softmax,
                       scatter_std, segment_coo, segment_csr)
-from . import autograd
+from . import autograd, layers
 from .aten import install, uninstall, installed
 
 __all__ = [
@@ -44,5 +44,5 @@ __all__ = [
     "scatter_max", "scatter_mean", "scatter_min", "scatter_mul", "scatter_reduce_mul_", "scatter_sum",
     "set_plan_cache", "install", "uninstall", "installed", "coalesce", "coalesce_sparse_tensor", "sort", "sparse_mm",
     "spmm", "spmm_csr", "spspmm", "transpose", "transpose_contiguous", "addmm", "matmul", "index_add_select_sum", "segment_csr", "segment_coo", "gather_csr", "gather_coo",
-    "rowptr_from_sorted", "scatter_softmax", "scatter_log_softmax", "scatter_logsumexp", "scatter_std", "autograd",
+    "rowptr_from_sorted", "scatter_softmax", "scatter_log_softmax", "scatter_logsumexp", "scatter_std", "autograd", "layers",
 ]

@@ -101,6 +101,30 @@ class Plan:
         check(rc, "plan_build")
         # ws is returned to the caching allocator here; stream-ordered reuse keeps that safe.
 
+    # --- persistence: a plan of a static edge_index can be built once and shipped with the dataset ---
+    def state_dict(self):
+        return {"rowptr": self.rowptr.cpu(), "perm": self.perm[: max(self.E, 0)].cpu(), "E": self.E, "N": self.N, "format": 1}
+
+    @classmethod
+    def from_state_dict(cls, state, device="cuda"):
+        if state.get("format") != 1:
+            raise ValueError("Plan.from_state_dict: unknown format")
+        self = object.__new__(cls)
+        self.E, self.N = int(state["E"]), int(state["N"])
+        self.rowptr = state["rowptr"].to(device=device, dtype=torch.int32).contiguous()
+        perm = state["perm"].to(device=device, dtype=torch.int32).contiguous()
+        self.perm = perm if perm.numel() else torch.empty(1, dtype=torch.int32, device=device)
+        if self.rowptr.numel() != self.N + 1 or perm.numel() != self.E:
+            raise ValueError("Plan.from_state_dict: inconsistent sizes")
+        return self
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    @classmethod
+    def load(cls, path, device="cuda"):
+        return cls.from_state_dict(torch.load(path, map_location="cpu", weights_only=True), device)
+
 
 _plan_cache = {}          # id(index tensor) -> (weakref, version, N, Plan)
 _plan_cache_enabled = True
