@@ -19,7 +19,7 @@ namespace {
 
 constexpr int U = 8;
 
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ perm,
                                                         const int64_t* __restrict__ col, const T* __restrict__ value,
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (c[u] >= 0) rows[u] = *reinterpret_cast<const u32x4*>(mat + c[u] * D + c0);
+                if (c[u] >= 0) rows[u] = load16<NT>(mat + c[u] * D + c0);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (c[u] >= 0) {
@@ -89,9 +89,16 @@ __global__ __launch_bounds__(256) void spmm_elems_kernel(const int32_t* __restri
     }
 }
 
+// CSR materialisation of a plan-ordered COO operand: out[j] = in[perm[j]] for the column ids (8 B) or the values.
+template <typename U>
+__global__ void permute_kernel(const U* __restrict__ in, const int32_t* __restrict__ perm, U* __restrict__ out, int64_t n) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        out[j] = in[perm[j]];
+}
+
 template <typename T>
 int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value, const void* mat,
-           void* out, int64_t M, int64_t D, hipStream_t stream) {
+           void* out, int64_t M, int64_t D, int64_t mat_rows, hipStream_t stream) {
     constexpr int VEC = Elem<T>::VEC;
     if (D % VEC == 0 && (uintptr_t)mat % 16 == 0 && (uintptr_t)out % 16 == 0) {
         const int64_t vecs = D / VEC;
@@ -99,8 +106,15 @@ int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const
         while ((1 << gshift) < vecs && gshift < 6) ++gshift;
         const int kchunks = (int)gnnops_cdiv(vecs, (int64_t)1 << gshift);
         const int grid = gnnops_grid_cap(gnnops_cdiv((int64_t)kchunks * M, 256 >> gshift), 256 * 64);
-        hipLaunchKernelGGL((spmm_rows_kernel<T>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col, (const T*)value,
-                           (const T*)mat, (T*)out, M, D, gshift, kchunks);
+        // a dense operand far beyond the 256 MiB Infinity Cache is streamed nontemporally (its rows would only evict
+        // the CSR arrays); a smaller one keeps normal caching so repeated rows hit on-die
+        const bool nt = (size_t)mat_rows * (size_t)D * sizeof(T) > ((size_t)2 << 30);
+        if (nt)
+            hipLaunchKernelGGL((spmm_rows_kernel<T, true>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col,
+                               (const T*)value, (const T*)mat, (T*)out, M, D, gshift, kchunks);
+        else
+            hipLaunchKernelGGL((spmm_rows_kernel<T, false>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col,
+                               (const T*)value, (const T*)mat, (T*)out, M, D, gshift, kchunks);
     } else {
         const int grid = gnnops_grid_cap(gnnops_cdiv(M * D, 256), 256 * 32);
         hipLaunchKernelGGL((spmm_elems_kernel<T>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col, (const T*)value,
@@ -112,7 +126,7 @@ int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const
 }  // namespace
 
 extern "C" int gnnops_spmm(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value,
-                           const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int dtype,
+                           const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int64_t mat_rows, int dtype,
                            gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(M >= 0 && D >= 0 && nnz >= 0, GNNOPS_EINVAL, "spmm: negative size");
@@ -120,10 +134,28 @@ extern "C" int gnnops_spmm(const int32_t* rowptr, const int32_t* perm, const int
     if (M * D == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(rowptr && out && (nnz == 0 || (col && mat)), GNNOPS_EINVAL, "spmm: null pointer");
     switch (dtype) {
-        case GNNOPS_F32: return launch<float>(rowptr, perm, col, value, mat, out, M, D, stream);
-        case GNNOPS_F16: return launch<__half>(rowptr, perm, col, value, mat, out, M, D, stream);
-        case GNNOPS_BF16: return launch<__hip_bfloat16>(rowptr, perm, col, value, mat, out, M, D, stream);
+        case GNNOPS_F32: return launch<float>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream);
+        case GNNOPS_F16: return launch<__half>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream);
+        case GNNOPS_BF16: return launch<__hip_bfloat16>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream);
     }
     gnnops_set_error("spmm: unknown dtype %d", dtype);
     return GNNOPS_EINVAL;
+}
+
+// out[j] = in[perm[j]], elements of 2, 4 or 8 bytes: turns (plan, COO columns / values) into CSR arrays once, so the
+// row-split kernel streams them instead of chasing perm -> col for every nonzero.
+extern "C" int gnnops_permute(const void* in, const int32_t* perm, void* out, int64_t n, int elem_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(n >= 0, GNNOPS_EINVAL, "permute: negative size");
+    GNNOPS_REQUIRE(elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, GNNOPS_EUNSUPPORTED, "permute: elem_bytes %d", elem_bytes);
+    if (n == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(in && perm && out, GNNOPS_EINVAL, "permute: null pointer");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(n, 256), 256 * 32);
+    if (elem_bytes == 8)
+        hipLaunchKernelGGL(permute_kernel<uint64_t>, dim3(grid), dim3(256), 0, stream, (const uint64_t*)in, perm, (uint64_t*)out, n);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL(permute_kernel<uint32_t>, dim3(grid), dim3(256), 0, stream, (const uint32_t*)in, perm, (uint32_t*)out, n);
+    else
+        hipLaunchKernelGGL(permute_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)in, perm, (uint16_t*)out, n);
+    return gnnops_check_launch("permute");
 }

@@ -14,8 +14,7 @@ def propagate_sum(x, edge_index, num_nodes=None):
     """out[i] = sum_{(j -> i) in edge_index} x[j]; edge_index int64 [2, E] = (source row j, destination row i)."""
     if num_nodes is None:
         num_nodes = x.size(0)
-    index = torch.stack([edge_index[1], edge_index[0]])  # spmm's (row = destination, col = source)
-    return sparse.spmm(index, None, num_nodes, x.size(0), x)
+    return sparse.spmm_t(edge_index, None, x.size(0), num_nodes, x)  # plan cached under the edge_index tensor
 
 
 def propagate_mean(x, edge_index, num_nodes=None):

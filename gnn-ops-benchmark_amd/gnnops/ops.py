@@ -79,7 +79,7 @@ class Plan:
     (scatter_*, index_add_, index_select push form) — build it once per static edge_index.
     """
 
-    __slots__ = ("rowptr", "perm", "E", "N", "__weakref__")
+    __slots__ = ("rowptr", "perm", "E", "N", "_csr", "__weakref__")
 
     def __init__(self, index, N):
         _require_gpu(index)
@@ -143,19 +143,24 @@ def clear_plan_cache():
     _plan_cache.clear()
 
 
-def get_plan(index, N):
-    """Plan for ``index`` (cached per tensor object + version counter while the cache is enabled)."""
+def get_plan(index, N, owner=None, tag=0):
+    """Plan for ``index`` (cached per tensor object + version counter while the cache is enabled).
+
+    ``owner`` (default: ``index`` itself) is the tensor object the cache entry is tied to: a row of a COO
+    ``edge_index`` is a fresh view object on every call, so its plan is cached under the [2, E] parent, with ``tag``
+    telling the rows apart."""
     if isinstance(index, Plan):
         if index.N != N:
             raise ValueError(f"Plan was built for N={index.N}, op needs N={N}")
         return index
     if not _plan_cache_enabled:
         return Plan(index, N)
-    key = id(index)
+    owner = index if owner is None else owner
+    key = (id(owner), tag)
     hit = _plan_cache.get(key)
     if hit is not None:
         ref, version, n, plan = hit
-        if ref() is index and version == index._version and n == N:
+        if ref() is owner and version == owner._version and n == N:
             return plan
     plan = Plan(index, N)
     if len(_plan_cache) >= _PLAN_CACHE_MAX:
@@ -164,7 +169,7 @@ def get_plan(index, N):
     def _drop(_ref, key=key):
         _plan_cache.pop(key, None)
 
-    _plan_cache[key] = (weakref.ref(index, _drop), index._version, N, plan)
+    _plan_cache[key] = (weakref.ref(owner, _drop), owner._version, N, plan)
     return plan
 
 

@@ -32,8 +32,21 @@ def spmm(index, value, m, n, matrix):
     if value is not None and value.dtype != matrix.dtype:
         raise RuntimeError("spmm: value and matrix must have the same dtype")
     matrix = matrix.contiguous()
-    plan = get_plan(row, m)  # COO -> CSR view (rowptr, perm), stable
-    return _spmm_launch(plan.rowptr, plan.perm, col, value, matrix, m, dt)
+    plan = get_plan(row, m, owner=index, tag=0)  # COO -> CSR view (rowptr, perm), stable; cached under the [2, nnz] tensor
+    return _spmm_launch(plan.rowptr, plan.perm, col, value, matrix, m, dt, plan)
+
+
+def spmm_t(index, value, m, n, matrix):
+    """(n x m)^T-side product without materialising the transposed index: out[i] = sum over entries (j, i) of
+    value * matrix[j], i.e. rows of the result follow index[1] and the gathered rows follow index[0]. This is
+    message passing over a PyG-style edge_index = (source, destination): out [n, D], matrix [m, D]."""
+    _require_gpu(index, value, matrix)
+    index, src_rows, dst_rows = _coo_rows_cols(index, "spmm_t")
+    if matrix.dim() != 2 or matrix.size(0) != m:
+        raise RuntimeError("spmm_t: matrix must be [m, D]")
+    dt = _dtype_code(matrix, "spmm_t")
+    plan = get_plan(dst_rows, n, owner=index, tag=1)
+    return _spmm_launch(plan.rowptr, plan.perm, src_rows, value, matrix.contiguous(), n, dt, plan)
 
 
 def spmm_csr(rowptr, col, value, matrix):
@@ -48,14 +61,42 @@ def spmm_csr(rowptr, col, value, matrix):
     return _spmm_launch(rowptr.contiguous(), None, col.contiguous(), value, matrix.contiguous(), rowptr.numel() - 1, dt)
 
 
-def _spmm_launch(rowptr, perm, col, value, matrix, m, dt):
+def _permute(t, perm, n):
+    out = torch.empty(n, dtype=t.dtype, device=t.device)
+    with torch.cuda.device(t.device):
+        check(_lib.load().gnnops_permute(t.data_ptr(), perm.data_ptr(), out.data_ptr(), n, t.element_size(), _stream()), "permute")
+    return out
+
+
+def _csr_arrays(plan, col, value):
+    """CSR column ids (and values) of a COO operand in plan order, cached on the plan per (col, value) tensor version."""
+    key = (id(col), col._version, None if value is None else (id(value), value._version))
+    cached = getattr(plan, "_csr", None)
+    if cached is not None and cached[0] == key and cached[1]() is col and (value is None or cached[2]() is value):
+        return cached[3], cached[4]
+    n = col.numel()
+    col_csr = _permute(col, plan.perm, n)
+    val_csr = _permute(value.contiguous(), plan.perm, n) if value is not None else None
+    import weakref
+
+    try:
+        plan._csr = (key, weakref.ref(col), weakref.ref(value) if value is not None else None, col_csr, val_csr)
+    except AttributeError:
+        pass
+    return col_csr, val_csr
+
+
+def _spmm_launch(rowptr, perm, col, value, matrix, m, dt, plan=None):
+    if perm is not None and plan is not None and col.numel() > 0:
+        col, value = _csr_arrays(plan, col, value)  # stream CSR arrays instead of chasing perm -> col per nonzero
+        perm = None
     D = matrix.size(1)
     out = torch.empty((m, D), dtype=matrix.dtype, device=matrix.device)
     value_c = value.contiguous() if value is not None else None
     with torch.cuda.device(matrix.device):
         rc = _lib.load().gnnops_spmm(rowptr.data_ptr(), perm.data_ptr() if perm is not None else None, col.data_ptr(),
                                      value_c.data_ptr() if value_c is not None else None, matrix.data_ptr(),
-                                     out.data_ptr(), m, D, col.numel(), dt, _stream())
+                                     out.data_ptr(), m, D, col.numel(), matrix.size(0), dt, _stream())
     check(rc, "spmm")
     return out
 

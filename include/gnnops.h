@@ -147,11 +147,15 @@ int gnnops_fused_index_select_sum(const void* input, const int64_t* index, float
  * (benchmark_sparse_spmm.py:12-14; BASELINE config 3). Row-split over a CSR view of the sparse operand:
  *   out[i,:] = sum_{j in [rowptr[i], rowptr[i+1])} value[e_j] * mat[col[e_j], :],  e_j = perm ? perm[j] : j
  * so a CSR matrix passes perm = NULL and a COO matrix passes the plan of its row index (rowptr, perm).
- * value == NULL means all ones. mat [n, D], out [M, D]; fp32 accumulation, one rounding.
+ * value == NULL means all ones. mat [mat_rows, D], out [M, D]; fp32 accumulation, one rounding.
  * ------------------------------------------------------------------------------------------- */
 int gnnops_spmm(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value,
-                const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int dtype,
+                const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int64_t mat_rows, int dtype,
                 gnnops_stream_t stream);
+
+/* out[j] = in[perm[j]] (elements of 2, 4 or 8 bytes): materialises the CSR column / value arrays of a plan-ordered COO
+ * operand once, so gnnops_spmm can be called with perm == NULL and stream them. */
+int gnnops_permute(const void* in, const int32_t* perm, void* out, int64_t n, int elem_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch.sort(input, dim, descending, stable) (benchmark_native_sort.py:28-30 times fp32). input viewed

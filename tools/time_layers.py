@@ -20,5 +20,4 @@ gnnops.set_plan_cache(False)
 t("unfused cold: index_select + scatter_add (plans rebuilt)", lambda: gnnops.scatter_add(gnnops.index_select(x, 0, src_idx), dst_idx, 0, dim_size=N))
 t("fused cold: propagate_sum = one spmm (plan rebuilt)", lambda: gnnops.layers.propagate_sum(x, ei, N))
 gnnops.set_plan_cache(True)
-idx2 = torch.stack([dst_idx, src_idx])
-t("fused warm: spmm over a cached plan", lambda: gnnops.spmm(idx2, None, N, N, x))
+t("fused warm: propagate_sum, plan cached under edge_index", lambda: gnnops.layers.propagate_sum(x, ei, N))
