@@ -165,7 +165,7 @@ int launch_gather_lds(const void* in, const int64_t* index, void* out, int64_t B
 // ---- fused index_select + sum ----
 constexpr int FUSED_BLOCKS = 256 * 8;
 
-template <typename T>
+template <typename T, int RIF>
 __global__ __launch_bounds__(256) void select_sum_rows_kernel(const T* __restrict__ in, const int64_t* __restrict__ index,
                                                               float* __restrict__ partial, int64_t B, int64_t N,
                                                               int64_t K, int64_t E, int gshift, int chunks) {
@@ -177,10 +177,10 @@ __global__ __launch_bounds__(256) void select_sum_rows_kernel(const T* __restric
     const int gl = (int)(gtid & (G - 1));
     const int64_t items = B * (int64_t)chunks * E;
     float acc = 0.f;
-    for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * ROWS_IN_FLIGHT) {
-        const T* p[ROWS_IN_FLIGHT];
+    for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * RIF) {
+        const T* p[RIF];
 #pragma unroll
-        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+        for (int u = 0; u < RIF; ++u) {
             const int64_t item = item0 + (int64_t)u * ngroups;
             p[u] = nullptr;
             if (item < items) {
@@ -192,12 +192,12 @@ __global__ __launch_bounds__(256) void select_sum_rows_kernel(const T* __restric
                 if (col < K) p[u] = in + (b * N + index[e]) * K + col;
             }
         }
-        u32x4 v[ROWS_IN_FLIGHT];
+        u32x4 v[RIF];
 #pragma unroll
-        for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
+        for (int u = 0; u < RIF; ++u)
             if (p[u]) v[u] = load16<true>(p[u]);
 #pragma unroll
-        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+        for (int u = 0; u < RIF; ++u) {
             if (p[u]) {
                 float f[VEC];
                 Elem<T>::unpack(v[u], f);
@@ -290,9 +290,10 @@ int launch_select_sum(const void* input, const int64_t* index, float* d_sum, int
     if (K % VEC == 0 && (uintptr_t)input % 16 == 0) {
         RowGeom g = row_geom(K / VEC);
         const int64_t items = B * g.chunks * E;
+        // 4 rows in flight per lane group: 2 and 4 tie, 8 loses a third (register pressure) — tools/time_selsum.py
         grid = gnnops_grid_cap(gnnops_cdiv(items, (256 >> g.gshift) * ROWS_IN_FLIGHT), FUSED_BLOCKS);
-        hipLaunchKernelGGL((select_sum_rows_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)input, index,
-                           partial, B, N, K, E, g.gshift, g.chunks);
+        hipLaunchKernelGGL((select_sum_rows_kernel<T, ROWS_IN_FLIGHT>), dim3(grid), dim3(256), 0, stream, (const T*)input,
+                           index, partial, B, N, K, E, g.gshift, g.chunks);
     } else if (K == 1 && (size_t)N * sizeof(T) <= GL_BUDGET && E * 4 >= N) {
         static bool configured = false;
         if (!configured) {
