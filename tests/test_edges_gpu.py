@@ -160,3 +160,36 @@ def test_byte_movers_take_any_real_dtype(gnnops):
         assert torch.equal(torch.index_select(ei, 1, perm), ei[:, perm])
     finally:
         gnnops.uninstall()
+
+
+def test_less_travelled_shapes(gnnops, oracle):
+    """Paths the main suites touch lightly: push-form index_select with batch and > 1 KiB rows, coalesce with vector
+    values, spmm with a 1-D operand, composite ops along a middle / last dim."""
+    g = torch.Generator().manual_seed(41)
+    x = torch.rand(3, 200, 320, generator=g)                      # B = 3, rows of 1280 B: two column chunks
+    idx = torch.randint(0, 200, (700,), generator=g)
+    plan = gnnops.Plan(idx.cuda(), 200)
+    got = gnnops.index_select(x.cuda(), 1, idx.cuda(), plan=plan)
+    assert_bits_equal(got.cpu().numpy(), oracle.index_select(x.numpy(), 1, idx.numpy()), "push form, batch, wide rows")
+    coo = torch.stack([torch.randint(0, 30, (400,), generator=g), torch.randint(0, 20, (400,), generator=g)])
+    val = torch.rand(400, 3, generator=g)
+    ci, cv = gnnops.coalesce(coo.cuda(), val.cuda(), 30, 20)
+    ei, ev = oracle.coalesce(coo.numpy(), val.numpy(), 30, 20)
+    assert_bits_equal(ci.cpu().numpy(), ei, "coalesce index") and assert_bits_equal(cv.cpu().numpy(), ev, "coalesce [nnz, 3] values")
+    vec = torch.rand(20, generator=g)
+    v1 = torch.rand(400, generator=g)
+    got = gnnops.spmm(coo.cuda(), v1.cuda(), 30, 20, vec.cuda())
+    assert got.shape == (30,)
+    assert_bits_equal(got.cpu().numpy(), oracle.spmm(coo.numpy(), v1.numpy(), 30, 20, vec.numpy().reshape(20, 1)).reshape(30), "spmm vector")
+    import torch_scatter
+
+    src = torch.randn(4, 300, 6, generator=g)
+    idx2 = torch.randint(0, 17, (300,), generator=g)
+    sm = torch_scatter.scatter_softmax(src.cuda(), idx2.cuda(), dim=1, dim_size=17).cpu()
+    lse = torch_scatter.scatter_logsumexp(src.cuda(), idx2.cuda(), dim=1, dim_size=17).cpu()
+    for b in range(4):
+        np.testing.assert_allclose(sm[b].numpy(), oracle.composite(src[b].numpy(), idx2.numpy(), 17, "softmax"), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(lse[b].numpy(), oracle.composite(src[b].numpy(), idx2.numpy(), 17, "logsumexp"), rtol=2e-6, atol=2e-6)
+    last = torch.randn(50, 400, generator=g)                      # dim = -1: K = 1
+    sd = torch_scatter.scatter_std(last.cuda(), torch.randint(0, 9, (400,), generator=g).cuda(), dim=-1, dim_size=9)
+    assert sd.shape == (50, 9) and torch.isfinite(sd).all()
