@@ -335,7 +335,7 @@ def cpu_baseline_leg(D):
         if dt > 10.0 or reps >= 20:
             break
     alg = algorithmic_bytes("scatter_add", Ns, Es, D)
-    return {
+    res = {
         "value": round(alg * reps / dt / 1e9, 3),
         "unit": "GB/s",
         "cores": 1,
@@ -343,6 +343,24 @@ def cpu_baseline_leg(D):
         "sample": f"oracle/gnnops_oracle.c ora_scatter_add_rows_f32, N={Ns} E={Es} D={D} fp32 (1/10 of config 2), "
                   f"{reps} passes in {dt:.1f} s on one of {os.cpu_count()} host cores",
     }
+    # Beside it: what the reference's op body executes on CPU tensors (torch_scatter.scatter_add forwards to
+    # Tensor.scatter_add_ / index_add_), PyTorch's own CPU kernel with its default thread count, same sample.
+    try:
+        import torch
+
+        tsrc, tidx = torch.from_numpy(src), torch.from_numpy(idx)
+        torch.zeros(Ns, D).index_add_(0, tidx, tsrc)
+        t0 = time.perf_counter()
+        treps = 0
+        while time.perf_counter() - t0 < 5.0 and treps < 20:
+            torch.zeros(Ns, D).index_add_(0, tidx, tsrc)
+            treps += 1
+        tdt = time.perf_counter() - t0
+        res["torch_cpu"] = {"value": round(alg * treps / tdt / 1e9, 3), "unit": "GB/s", "threads": torch.get_num_threads(),
+                            "op": "torch.zeros(N, D).index_add_(0, index, src)"}
+    except Exception as exc:  # reporting extra only
+        res["torch_cpu"] = {"error": str(exc)[:200]}
+    return res
 
 
 if __name__ == "__main__":
