@@ -4,7 +4,9 @@ Reference call sites: torch.index_select (op_bm_scripts/benchmark_native_index_s
 Tensor.index_add_ (benchmark_native_index_add_.py:15), torch.gather (benchmark_native_gather.py:16),
 Tensor.scatter_add_ (benchmark_scatter_add.py:24), torch.index_add
 (benchmark_fused_index_add_reduce.py:13), torch.sort (benchmark_native_sort.py:29), torch.addmm / torch.matmul
-(benchmark_native_addmm.py:15, benchmark_native_matmul.py:15).
+(benchmark_native_addmm.py:15, benchmark_native_matmul.py:15), Tensor.scatter_(reduce="multiply")
+(benchmark_scatter_multiply.py:44), and — on the SparseCUDA key — torch.sparse.mm with a dense or a sparse right operand
+(benchmark_sparse_spmm.py:13, benchmark_sparse_spspmm.py:13) and Tensor.coalesce() (benchmark_sparse_coalesce.py:41).
 
 ROCm builds of PyTorch register device kernels under the "CUDA" dispatch key, so overriding that key is
 what makes ``device="cuda"`` script text reach our kernels. ``install()`` is reversible: ``uninstall()``
@@ -16,6 +18,7 @@ import torch
 from . import ops
 
 _library = None
+routed_ops = set()   # names overridden by the last install()
 
 
 def installed():
@@ -27,6 +30,7 @@ def install():
     if _library is not None:
         return
     lib = torch.library.Library("aten", "IMPL")
+    routed = set()
 
     def index_select(self, dim, index):
         return ops.index_select(self, dim, index)
@@ -62,6 +66,45 @@ def install():
     def mm(self, mat2):
         return ops.matmul(self, mat2)
 
+    def scatter_reduce_(self, dim, index, src, *, reduce):
+        # Tensor.scatter_(dim, index, src, reduce="add" | "multiply") (benchmark_scatter_multiply.py:44)
+        if reduce == "add":
+            return ops.scatter_add_(self, dim, index, src)
+        if reduce == "multiply":
+            return ops.scatter_reduce_mul_(self, dim, index, src)
+        raise NotImplementedError(f"gnnops: scatter_(reduce={reduce!r}) is not supported")
+
+    def sparse_mm(sparse, dense):
+        from . import sparse as sp
+
+        return sp.sparse_mm(sparse, dense)
+
+    def sparse_coalesce(self):
+        from . import sparse as sp
+
+        return sp.coalesce_sparse_tensor(self)
+
+    lib.impl("scatter_.reduce", scatter_reduce_, "CUDA")
+    routed.update({"scatter_.reduce"})
+    # sparse COO operands dispatch on the SparseCUDA key (torch.sparse.mm, Tensor.coalesce()); optional: a build
+    # that refuses these registrations keeps its stock kernels and gnnops.sparse_mm / coalesce_sparse_tensor stay
+    # available by name
+    def sparse_addmm(self, mat1, mat2, *, beta=1, alpha=1):
+        # torch.sparse.mm(S, D) lowers to addmm(zeros, S, D, beta=0, alpha=1) on the sparse key
+        from . import sparse as sp
+
+        prod = sp.sparse_mm(mat1, mat2)
+        if alpha != 1:
+            prod = prod * alpha
+        return prod if beta == 0 else prod + beta * self
+
+    for name, fn in (("_sparse_mm", sparse_mm), ("addmm", sparse_addmm), ("_sparse_sparse_matmul", sparse_mm),
+                     ("_coalesce", sparse_coalesce)):
+        try:
+            lib.impl(name, fn, "SparseCUDA")
+            routed.add(name + "@SparseCUDA")
+        except Exception:  # pragma: no cover - depends on the torch build
+            pass
     lib.impl("sort.stable", sort_stable, "CUDA")
     lib.impl("sort", sort_default, "CUDA")
     lib.impl("addmm", addmm, "CUDA")
@@ -73,6 +116,9 @@ def install():
     lib.impl("scatter_add_", scatter_add_, "CUDA")
     lib.impl("scatter_add", scatter_add, "CUDA")
     _library = lib
+    global routed_ops
+    routed_ops = routed | {"index_select", "gather", "index_add_", "index_add", "scatter_add_", "scatter_add", "sort",
+                           "sort.stable", "addmm", "mm"}
 
 
 def uninstall():
@@ -80,3 +126,4 @@ def uninstall():
     if _library is not None:
         _library._destroy()
         _library = None
+routed_ops = set()   # names overridden by the last install()

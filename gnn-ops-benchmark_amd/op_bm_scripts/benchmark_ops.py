@@ -43,7 +43,7 @@ def op_scatter_mean(src, idx, dim):           # benchmark_scatter_mean.py:15-18
     return torch_scatter.scatter_mean(src, idx, dim)
 def op_native_scatter_multiply_(src, idx):    # benchmark_scatter_multiply.py:42-45
     temp = torch.zeros_like(src)
-    gnnops.scatter_reduce_mul_(temp, -1, idx, src)
+    temp.scatter_(-1, idx, src, reduce="multiply")
 def op_native_index_select(input, dim, index):  # benchmark_native_index_select.py:12-15
     return torch.index_select(input, dim, index)
 def op_native_index_add_(input, dim, index, source):  # benchmark_native_index_add_.py:13-16
@@ -53,7 +53,7 @@ def op_native_gather(input, dim, index):      # benchmark_native_gather.py:14-17
 def op_native_sort(input, dim, stable):       # benchmark_native_sort.py:28-30
     return torch.sort(input, dim=dim, stable=stable)
 def op_native_smm(matA, matB):                # benchmark_sparse_spmm.py:12-14 / benchmark_sparse_spspmm.py:12-14
-    return gnnops.sparse_mm(matA, matB)
+    return torch.sparse.mm(matA, matB)
 def op_sparse_coalesce(index, value, m, n):   # benchmark_sparse_coalesce.py:35-37
     return torch_sparse.coalesce(index=index, value=value, m=m, n=n)
 def op_native_transpose(matA):                # benchmark_sparse_transpose.py:13-16

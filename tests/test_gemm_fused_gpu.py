@@ -123,3 +123,47 @@ def test_addmm_fp32(gnnops, M, N, K):
     Bi = (torch.arange(n * n).view(n, n) % 1009).float()
     assert torch.equal(gnnops.matmul(torch.eye(n).cuda(), Bi.cuda()).cpu(), Bi)
     assert torch.equal(gnnops.matmul(Bi.cuda(), torch.eye(n).cuda()).cpu(), Bi)
+
+
+def test_aten_sparse_and_scatter_reduce_overrides(gnnops, monkeypatch):
+    """torch.sparse.mm, Tensor.coalesce() and Tensor.scatter_(reduce=...) reach our kernels when the build accepts the
+    SparseCUDA registrations (otherwise the by-name entry points remain): verified by counting calls."""
+    from gnnops import aten, sparse as sp, ops
+
+    calls = {"mm": 0, "coalesce": 0, "mul": 0}
+    real_mm, real_co, real_mul = sp.sparse_mm, sp.coalesce_sparse_tensor, ops.scatter_reduce_mul_
+    monkeypatch.setattr(sp, "sparse_mm", lambda a, b: (calls.__setitem__("mm", calls["mm"] + 1), real_mm(a, b))[1])
+    monkeypatch.setattr(sp, "coalesce_sparse_tensor", lambda a: (calls.__setitem__("coalesce", calls["coalesce"] + 1), real_co(a))[1])
+    monkeypatch.setattr(ops, "scatter_reduce_mul_", lambda *a: (calls.__setitem__("mul", calls["mul"] + 1), real_mul(*a))[1])
+    g = torch.Generator().manual_seed(29)
+    dense = torch.nn.functional.dropout(torch.rand(200, 150, generator=g), p=0.9)
+    B = torch.rand(150, 32, generator=g)
+    idx = torch.stack([torch.randint(0, 200, (900,), generator=g), torch.randint(0, 150, (900,), generator=g)])
+    val = torch.rand(900, generator=g)
+    src = torch.rand(64, 48, generator=g)
+    full = torch.randint(0, 48, (64, 48), generator=g)
+    gnnops.install()
+    try:
+        A = dense.cuda().to_sparse()
+        out = torch.sparse.mm(A, B.cuda())
+        Bs = torch.nn.functional.dropout(torch.rand(150, 90, generator=g), p=0.9).cuda().to_sparse()
+        ss = torch.sparse.mm(A, Bs)
+        unc = torch.sparse_coo_tensor(idx.cuda(), val.cuda(), (200, 150))
+        co = unc.coalesce()
+        temp = torch.zeros_like(src).cuda()
+        temp.scatter_(-1, full.cuda(), src.cuda(), reduce="multiply")
+    finally:
+        gnnops.uninstall()
+    np.testing.assert_allclose(out.cpu().numpy(), (dense @ B).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ss.to_dense().cpu().numpy(), (dense @ Bs.to_dense().cpu()).numpy(), rtol=1e-5, atol=1e-5)
+    ref = torch.sparse_coo_tensor(idx, val, (200, 150)).coalesce()
+    assert torch.equal(co.indices().cpu(), ref.indices())
+    np.testing.assert_allclose(co.values().cpu().numpy(), ref.values().numpy(), rtol=1e-6)
+    assert torch.count_nonzero(temp).item() == 0 and calls["mul"] == 1
+    print("routed:", sorted(aten.routed_ops), calls)
+    if "addmm@SparseCUDA" in aten.routed_ops:
+        assert calls["mm"] >= 1
+    if "_sparse_sparse_matmul@SparseCUDA" in aten.routed_ops:
+        assert calls["mm"] >= 2
+    if "_coalesce@SparseCUDA" in aten.routed_ops:
+        assert calls["coalesce"] >= 1
