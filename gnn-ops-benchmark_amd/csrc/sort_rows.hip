@@ -1,0 +1,192 @@
+// sort_rows.hip — torch.sort along the LAST dimension when a row fits in LDS (E <= 22528 fp32 keys): one workgroup
+// sorts one row entirely on chip — the (20000, 20000) and 800^3 shapes of op_bm_scripts/benchmark_native_sort.py:37-45.
+//
+// The generic path (sort.hip) sorts (segment << 32 | key) with six or more passes over HBM. Here a row is read once
+// (4 B/element) and written once (4 B value + 8 B index); the four 8-bit LSD passes run between registers and LDS:
+//   rank   each wave owns consecutive rows of 64 keys; eight ballots give every lane its equal-digit peers, the lowest
+//          peer does one returning LDS add per distinct digit (same scheme as sort_engine_impl.h, stable)
+//   place  per-digit offsets across waves and digits, then (key, 16-bit position) go to their sorted slot in LDS
+//   reload every wave reads its slice of the sorted image back for the next pass
+// Stable; -0.0 / NaN conventions as in sort.hip. fp32 keys; positions fit 16 bits (E < 65536).
+#include "common.h"
+
+namespace {
+
+__device__ inline uint32_t f32_key(float x) {
+    uint32_t u = __float_as_uint(x);
+    if (u == 0x80000000u) u = 0u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float key_f32(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(u);
+}
+
+constexpr int RADIX = 256;
+
+// THREADS x ROUNDS keys per row at most; LDS: keys u32[CAP] + pos u16[CAP] + per-wave histograms.
+template <int THREADS, int ROUNDS>
+__global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restrict__ in, float* __restrict__ values,
+                                                            int64_t* __restrict__ indices, int64_t rows, int E,
+                                                            int descending) {
+    constexpr int WAVES = THREADS / 64;
+    constexpr int CAP = THREADS * ROUNDS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sr_raw[];
+    uint32_t* s_keys = reinterpret_cast<uint32_t*>(sr_raw);
+    uint16_t* s_pos = reinterpret_cast<uint16_t*>(sr_raw + (size_t)CAP * 4);
+    uint32_t* s_whist = reinterpret_cast<uint32_t*>(sr_raw + (size_t)CAP * 6);  // [WAVES][RADIX]
+    uint32_t* s_tmp = s_whist + WAVES * RADIX;                                     // [WAVES]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int wave_base = wave * ROUNDS * 64;
+    uint32_t* whist = s_whist + wave * RADIX;
+
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* src = in + row * E;
+        uint32_t key[ROUNDS];
+        uint32_t px[ROUNDS];  // source position in the high half; the low half is scratch for the ranking
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int i = wave_base + r * 64 + lane;
+            uint32_t k = (i < E) ? f32_key(src[i]) : 0u;
+            key[r] = descending ? ~k : k;
+            px[r] = (uint32_t)i << 16;
+        }
+#pragma unroll 1
+        for (int shift = 0; shift < 32; shift += 8) {
+            __syncthreads();  // previous pass's reloads (and the previous row's stores) are done with LDS
+            for (int i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
+            __syncthreads();
+            // rank inside the wave
+            uint32_t is_leader = 0;
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int i = wave_base + r * 64 + lane;
+                const bool valid = i < E;
+                const uint32_t d = (key[r] >> shift) & 255u;
+                const uint64_t vb = __ballot(valid);
+                uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+                    const uint64_t bal = __ballot(xb != 0u);
+                    m_lo &= ~((uint32_t)bal ^ xb);
+                    m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
+                }
+                const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
+                const uint32_t below = __popcll(m & lanes_below);
+                uint32_t lo;  // 16 bits: the LDS add's return (leader) or below | leader_lane << 8 (others)
+                if (valid && below == 0) {
+                    lo = atomicAdd(&whist[d], (uint32_t)__popcll(m));
+                    is_leader |= 1u << r;
+                } else {
+                    lo = below | ((uint32_t)(__ffsll((unsigned long long)m) - 1) << 8);
+                }
+                px[r] = (px[r] & 0xffff0000u) | (lo & 0xffffu);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const bool lead = (is_leader >> r) & 1u;
+                const uint32_t lo = px[r] & 0xffffu;
+                const int from = lead ? lane : (int)((lo >> 8) & 63u);
+                const uint32_t p = __shfl(lo, from);
+                const uint32_t rank = lead ? p : p + (lo & 255u);  // rank among equal digits of this wave
+                px[r] = (px[r] & 0xffff0000u) | rank;
+            }
+            __syncthreads();
+            // digit offsets: exclusive over waves, then over digits
+            {
+                const int d = tid & (RADIX - 1);
+                const bool act = tid < RADIX;
+                uint32_t tot = 0;
+                if (act) {
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) {
+                        const uint32_t c = s_whist[w * RADIX + d];
+                        s_whist[w * RADIX + d] = tot;
+                        tot += c;
+                    }
+                }
+                const uint32_t start = block_excl_scan_u32<WAVES>(act ? tot : 0u, s_tmp, nullptr);
+                if (act) {
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + d] += start;
+                }
+            }
+            __syncthreads();
+            // place
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int i = wave_base + r * 64 + lane;
+                if (i < E) {
+                    const uint32_t d = (key[r] >> shift) & 255u;
+                    const uint32_t p = whist[d] + (px[r] & 0xffffu);
+                    s_keys[p] = key[r];
+                    s_pos[p] = (uint16_t)(px[r] >> 16);
+                }
+            }
+            __syncthreads();
+            // reload this wave's slice of the sorted image
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int i = wave_base + r * 64 + lane;
+                if (i < E) {
+                    key[r] = s_keys[i];
+                    px[r] = (uint32_t)s_pos[i] << 16;
+                }
+            }
+        }
+        float* vdst = values + row * E;
+        int64_t* idst = indices + row * E;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int i = wave_base + r * 64 + lane;
+            if (i < E) {
+                vdst[i] = key_f32(descending ? ~key[r] : key[r]);
+                idst[i] = (int64_t)(px[r] >> 16);
+            }
+        }
+    }
+}
+
+template <int THREADS, int ROUNDS>
+int launch(const float* in, float* values, int64_t* indices, int64_t rows, int E, int descending, hipStream_t stream) {
+    constexpr int CAP = THREADS * ROUNDS;
+    constexpr size_t LDS = (size_t)CAP * 6 + (size_t)(THREADS / 64) * RADIX * 4 + 64 * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_rows_kernel<THREADS, ROUNDS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess)
+            return gnnops_check_launch("sort_rows attribute");
+        configured = true;
+    }
+    const int grid = gnnops_grid_cap(rows, 256 * 8);
+    hipLaunchKernelGGL((sort_rows_kernel<THREADS, ROUNDS>), dim3(grid), dim3(THREADS), LDS, stream, in, values, indices, rows,
+                       E, descending);
+    return gnnops_check_launch("sort_rows");
+}
+
+}  // namespace
+
+// Largest row length the on-chip form takes.
+extern "C" int64_t gnnops_sort_rows_max_len(void) { return 1024 * 22; }
+
+// input / values [rows, E] fp32, indices [rows, E] int64; sorted along E. E <= gnnops_sort_rows_max_len().
+extern "C" int gnnops_sort_rows_f32(const float* input, float* values, int64_t* indices, int64_t rows, int64_t E,
+                                    int descending, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(rows >= 0 && E >= 0, GNNOPS_EINVAL, "sort_rows: negative size");
+    GNNOPS_REQUIRE(E <= gnnops_sort_rows_max_len(), GNNOPS_EUNSUPPORTED, "sort_rows: row length %lld exceeds %lld",
+                   (long long)E, (long long)gnnops_sort_rows_max_len());
+    if (rows * E == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(input && values && indices, GNNOPS_EINVAL, "sort_rows: null pointer");
+    const int e = (int)E;
+    if (E <= 256 * 4) return launch<256, 4>(input, values, indices, rows, e, descending, stream);
+    if (E <= 1024 * 4) return launch<1024, 4>(input, values, indices, rows, e, descending, stream);
+    if (E <= 1024 * 8) return launch<1024, 8>(input, values, indices, rows, e, descending, stream);
+    if (E <= 1024 * 16) return launch<1024, 16>(input, values, indices, rows, e, descending, stream);
+    return launch<1024, 22>(input, values, indices, rows, e, descending, stream);
+}

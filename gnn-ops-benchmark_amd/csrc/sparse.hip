@@ -106,6 +106,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in
                                                         int64_t C) {
     __shared__ U tile[64][64 + (sizeof(U) >= 4 ? 1 : 4 / sizeof(U))];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    in += (int64_t)blockIdx.z * R * C;   // batch of independent [R, C] matrices
+    out += (int64_t)blockIdx.z * R * C;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -214,14 +216,28 @@ extern "C" int gnnops_coalesce(const int64_t* row, const int64_t* col, const voi
 }
 
 extern "C" int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes, gnnops_stream_t s) {
+    return gnnops_transpose_batched(in, out, 1, R, C, elem_bytes, s);
+}
+
+extern "C" int gnnops_transpose_batched(const void* in, void* out, int64_t batch, int64_t R, int64_t C, int elem_bytes,
+                                        gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
-    GNNOPS_REQUIRE(R >= 0 && C >= 0, GNNOPS_EINVAL, "transpose2d: negative size");
+    GNNOPS_REQUIRE(R >= 0 && C >= 0 && batch >= 0, GNNOPS_EINVAL, "transpose2d: negative size");
+    if (batch > 65535) {  // grid.z limit: split the batch
+        const int64_t bytes = R * C * elem_bytes;
+        for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+            const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+            const int rc = gnnops_transpose_batched((const char*)in + b0 * bytes, (char*)out + b0 * bytes, nb, R, C, elem_bytes, s);
+            if (rc) return rc;
+        }
+        return GNNOPS_OK;
+    }
     GNNOPS_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, GNNOPS_EUNSUPPORTED,
                    "transpose2d: elem_bytes %d", elem_bytes);
-    if (R * C == 0) return GNNOPS_OK;
+    if (R * C * batch == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(in && out, GNNOPS_EINVAL, "transpose2d: null pointer");
     GNNOPS_REQUIRE(gnnops_cdiv(R, 64) < 65536, GNNOPS_EUNSUPPORTED, "transpose2d: too many rows");
-    dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64));
+    dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64), (unsigned)batch);
     if (elem_bytes == 1)
         hipLaunchKernelGGL((transpose_kernel<uint8_t>), grid, dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, R, C);
     else if (elem_bytes == 2)

@@ -213,6 +213,26 @@ def transpose_contiguous(mat):
     return out
 
 
+def _transpose_batched(t3):
+    """[B, R, C] -> [B, C, R] contiguous (any 1/2/4/8-byte dtype)."""
+    Bn, R, C = t3.shape
+    out = torch.empty((Bn, C, R), dtype=t3.dtype, device=t3.device)
+    with torch.cuda.device(t3.device):
+        check(_lib.load().gnnops_transpose_batched(t3.data_ptr(), out.data_ptr(), Bn, R, C, t3.element_size(), _stream()),
+              "transpose_batched")
+    return out
+
+
+def _sort_rows(mat, descending, out_shape):
+    rows, E = mat.shape
+    values = torch.empty(out_shape, dtype=torch.float32, device=mat.device)
+    indices = torch.empty(out_shape, dtype=torch.int64, device=mat.device)
+    with torch.cuda.device(mat.device):
+        check(_lib.load().gnnops_sort_rows_f32(mat.data_ptr(), values.data_ptr(), indices.data_ptr(), rows, E,
+                                               1 if descending else 0, _stream()), "sort_rows")
+    return values, indices
+
+
 _SORT_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.int32: 3, torch.int64: 4, torch.float64: 5}
 
 
@@ -230,9 +250,16 @@ def sort(input, dim=-1, descending=False, stable=False):
     sd = _SORT_DT[input.dtype]
     if sd >= 4 and B * K != 1:
         raise NotImplementedError(f"gnnops.sort: {input.dtype} is sorted for 1-D tensors only")
+    L = _lib.load()
+    if input.dtype == torch.float32 and 32 <= E <= L.gnnops_sort_rows_max_len() and B * K > 1:
+        # rows that fit in LDS are sorted on chip; along dim 0 of a matrix via our tiled transposes
+        if K == 1:
+            return _sort_rows(input.view(B, E), descending, input.shape)
+        # [B, E, K] -> [B, K, E] by our tiled transposes, sort the B*K rows, transpose both results back
+        v, i = _sort_rows(_transpose_batched(input.view(B, E, K)).view(B * K, E), descending, (B, K, E))
+        return _transpose_batched(v).view(input.shape), _transpose_batched(i).view(input.shape)
     values = torch.empty_like(input)
     indices = torch.empty(input.shape, dtype=torch.int64, device=input.device)
-    L = _lib.load()
     ws_bytes = L.gnnops_sort_workspace_bytes(B, E, K, sd)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=input.device)
     with torch.cuda.device(input.device):

@@ -167,6 +167,12 @@ size_t gnnops_sort_workspace_bytes(int64_t B, int64_t E, int64_t K, int sort_dty
 int gnnops_sort(const void* input, void* values, int64_t* indices, int64_t B, int64_t E, int64_t K,
                 int sort_dtype, int descending, void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 
+/* On-chip form of the same op for fp32 rows that fit in LDS (E <= gnnops_sort_rows_max_len()): input / values
+ * [rows, E], indices int64 [rows, E], sorted along E; one HBM read and one write per element instead of 6+ passes. */
+int64_t gnnops_sort_rows_max_len(void);
+int gnnops_sort_rows_f32(const float* input, float* values, int64_t* indices, int64_t rows, int64_t E,
+                         int descending, gnnops_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * torch_sparse.coalesce(index, value, m, n, op="add") / Tensor.coalesce()
  * (benchmark_sparse_coalesce.py:35-42); torch_sparse.transpose = the same call with row/col swapped
@@ -184,6 +190,9 @@ int gnnops_coalesce(const int64_t* row, const int64_t* col, const void* value, i
  * in [R, C] -> out [C, R]; elem_bytes in {1, 2, 4, 8}; bit-exact. */
 int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes,
                        gnnops_stream_t stream);
+/* batch of independent [R, C] -> [C, R] copies (in / out [batch, R, C] / [batch, C, R]). */
+int gnnops_transpose_batched(const void* in, void* out, int64_t batch, int64_t R, int64_t C, int elem_bytes,
+                             gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch.addmm(input, mat1, mat2) / torch.matmul(input, other) on 16-bit operands

@@ -181,3 +181,30 @@ def test_sort_dtypes_and_descending(gnnops, dt, descending):
     v, i = gnnops.sort(big.cuda(), descending=descending)
     ev, ei = torch.sort(big, descending=descending, stable=True)
     assert torch.equal(v.cpu(), ev) and torch.equal(i.cpu(), ei)
+
+
+@pytest.mark.parametrize("rows,E", [(300, 1000), (50, 4096), (40, 8000), (20, 16384), (6, 20000), (3, 22528), (5000, 33), (7, 1025)])
+@pytest.mark.parametrize("descending", [False, True])
+def test_sort_rows_on_chip(gnnops, rows, E, descending):
+    """Rows that fit in LDS take the on-chip kernel (last dim), and dim 0 of a matrix goes through our transposes:
+    both bit-exact against torch.sort(stable=True) on the CPU, tie-heavy inputs included."""
+    g = torch.Generator().manual_seed(rows * 7 + E)
+    x = torch.nn.functional.dropout(torch.randn(rows, E, generator=g), p=0.6)
+    ev, ei = torch.sort(x, dim=1, descending=descending, stable=True)
+    v, i = gnnops.sort(x.cuda(), dim=1, descending=descending, stable=True)
+    assert torch.equal(i.cpu(), ei), "indices"
+    assert torch.equal(v.cpu(), ev), "values"
+    xt = x.t().contiguous()                       # sort along dim 0 of the transposed matrix
+    v0, i0 = gnnops.sort(xt.cuda(), dim=0, descending=descending, stable=True)
+    assert torch.equal(i0.cpu(), ei.t()) and torch.equal(v0.cpu(), ev.t())
+
+
+def test_sort_nd_non_last_dim_on_chip(gnnops, oracle):
+    """3-D, sorting along dims 0 and 1: batched transposes + on-chip rows, bit-exact vs the oracle."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.nn.functional.dropout(torch.randn(40, 70, 33, generator=g), p=0.5)
+    for dim in (0, 1, 2):
+        v, i = gnnops.sort(x.cuda(), dim=dim, stable=True)
+        ev, ei = oracle.sort(x.numpy(), dim)
+        assert_bits_equal(v.cpu().numpy(), ev, f"values d{dim}")
+        assert_bits_equal(i.cpu().numpy(), ei, f"indices d{dim}")
