@@ -127,3 +127,23 @@ def test_harness_mirror(tmp_path, capsys):
     df = pd.read_csv(tmp_path / "x.csv", index_col=0)
     assert list(df.columns) == ["p", "Input size (>95% mem util)*", "Sparsity", "GPU clock time"]
     assert df.iloc[0].tolist() == ["1;0;True", "(3, 3)", 0, 1.5]
+
+
+def test_product_never_touches_the_oracle_or_a_cpu_fallback():
+    """The oracle is test infrastructure: no module of the shipped package may import or load it, and no product source
+    may mention a CPU fallback path (static check over gnn-ops-benchmark_amd/)."""
+    pkg = os.path.join(ROOT, "gnn-ops-benchmark_amd")
+    offenders = []
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".h")):
+                continue
+            text = open(os.path.join(dirpath, f), errors="replace").read()
+            if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "liboracle" in text or "oracle/_build" in text:
+                offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
+    # the only users outside tests/: smoke() and bench.py's cpu_baseline leg
+    for name, needle in (("__graft_entry__.py", "def smoke"), ("bench.py", "def cpu_baseline_leg")):
+        text = open(os.path.join(ROOT, name)).read()
+        first_use = text.index("from oracle import oracle")
+        assert first_use > text.index(needle), f"{name}: oracle imported outside {needle}"
