@@ -107,6 +107,49 @@ class _Gather(torch.autograd.Function):
         return grad_in, None, None
 
 
+class _Composite(torch.autograd.Function):
+    """scatter_softmax / scatter_log_softmax / scatter_logsumexp over a row index along `dim`, differentiable in src.
+      softmax      dx = y * (g - sum_group(g * y))
+      log_softmax  dx = g - exp(y) * sum_group(g)
+      logsumexp    dx = g[group] * exp(x - out[group])
+    The group sums and the broadcasts back are our segment-reduce and index_select kernels over the same plan."""
+
+    @staticmethod
+    def forward(ctx, src, index, dim, dim_size, mode, eps):
+        from . import segment
+
+        dim = dim % src.dim()
+        row = ops._row_index_of(index, src, dim)
+        if row is None:
+            raise NotImplementedError("gnnops: composite ops take a row index")
+        N = int(dim_size) if dim_size is not None else (ops.index_max(row) + 1 if row.numel() else 0)
+        plan = ops.get_plan(row, N)
+        out = segment._composite(src, plan, dim, N, mode, eps)
+        ctx.save_for_backward(src, out, row)
+        ctx.plan, ctx.dim, ctx.mode = plan, dim, mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        src, out, row = ctx.saved_tensors
+        plan, dim, mode = ctx.plan, ctx.dim, ctx.mode
+        g = g.contiguous()
+        if mode == "softmax":
+            s = ops.scatter(g * out, plan, dim, None, None, "sum")
+            dx = out * (g - ops.index_select(s, dim, row))
+        elif mode == "log_softmax":
+            s = ops.scatter(g, plan, dim, None, None, "sum")
+            dx = g - out.exp() * ops.index_select(s, dim, row)
+        else:  # logsumexp: out has the group shape
+            dx = ops.index_select(g, dim, row) * (src - ops.index_select(out, dim, row)).exp()
+        return dx, None, None, None, None, None
+
+
+def composite(src, index, dim, dim_size, mode, eps):
+    """Differentiable entry for the composite ops (used by gnnops.segment when src requires grad)."""
+    return _Composite.apply(src, index, dim, dim_size, mode, eps)
+
+
 def _needs_grad(t):
     return torch.is_grad_enabled() and t.requires_grad
 

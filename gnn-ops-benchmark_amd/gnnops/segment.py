@@ -137,18 +137,26 @@ def _composite(src, index, dim, dim_size, mode, param):
     return out
 
 
+def _maybe_grad(src, index, dim, dim_size, mode, eps):
+    if torch.is_grad_enabled() and src.requires_grad and not isinstance(index, Plan):
+        from . import autograd
+
+        return autograd.composite(src, index, dim, dim_size, mode, eps)
+    return _composite(src, index, dim, dim_size, mode, eps)
+
+
 def scatter_softmax(src, index, dim=-1, dim_size=None):
-    return _composite(src, index, dim, dim_size, "softmax", 0.0)
+    return _maybe_grad(src, index, dim, dim_size, "softmax", 0.0)
 
 
 def scatter_log_softmax(src, index, dim=-1, eps=1e-12, dim_size=None):
-    return _composite(src, index, dim, dim_size, "log_softmax", eps)
+    return _maybe_grad(src, index, dim, dim_size, "log_softmax", eps)
 
 
 def scatter_logsumexp(src, index, dim=-1, out=None, dim_size=None, eps=1e-12):
     if out is not None:
         raise NotImplementedError("gnnops.scatter_logsumexp: out= is not supported")
-    return _composite(src, index, dim, dim_size, "logsumexp", eps)
+    return _maybe_grad(src, index, dim, dim_size, "logsumexp", eps)
 
 
 def scatter_std(src, index, dim=-1, out=None, dim_size=None, unbiased=True):

@@ -180,3 +180,36 @@ def test_layers_and_plan_persistence(gnnops, oracle, tmp_path):
     assert torch.equal(again.rowptr, plan.rowptr) and torch.equal(again.perm[:E], plan.perm[:E])
     src = torch.rand(E, 16, generator=g)
     assert torch.equal(gnnops.scatter_add(src.cuda(), again, 0), gnnops.scatter_add(src.cuda(), plan, 0))
+
+
+@pytest.mark.parametrize("mode", ["softmax", "log_softmax", "logsumexp"])
+def test_composite_backward(gnnops, mode):
+    """Gradients of the composite ops against torch-CPU autograd of the per-group torch formulation."""
+    import torch_scatter
+
+    g = torch.Generator().manual_seed(23)
+    E, N, K = 400, 30, 8
+    src = torch.randn(E, K, generator=g)
+    idx = torch.randint(0, N, (E,), generator=g)
+    idx[idx == 3] = 4
+    w = torch.rand(E if mode != "logsumexp" else N, K, generator=g)
+    ref_src = src.clone().requires_grad_(True)
+    total = torch.zeros(())
+    for n in range(N):
+        rows = torch.nonzero(idx == n).flatten()
+        if rows.numel() == 0:
+            continue
+        x = ref_src[rows]
+        if mode == "softmax":
+            total = total + (torch.softmax(x, 0) * w[rows]).sum()
+        elif mode == "log_softmax":
+            total = total + (torch.log_softmax(x, 0) * w[rows]).sum()
+        else:
+            total = total + (torch.logsumexp(x, 0) * w[n]).sum()
+    total.backward()
+    dsrc = src.clone().cuda().requires_grad_(True)
+    fn = {"softmax": torch_scatter.scatter_softmax, "log_softmax": torch_scatter.scatter_log_softmax,
+          "logsumexp": torch_scatter.scatter_logsumexp}[mode]
+    out = fn(dsrc, idx.cuda(), dim=0, dim_size=N)
+    (out * w.cuda()).sum().backward()
+    np.testing.assert_allclose(dsrc.grad.cpu().numpy(), ref_src.grad.numpy(), rtol=2e-5, atol=2e-6)
