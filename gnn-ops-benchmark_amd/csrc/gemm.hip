@@ -342,6 +342,318 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const uint16_t* __rest
     }
 }
 
+// Deeper pipeline for tile-aligned problems: BK = 32 and FOUR LDS stages, the LDS-DMA of tile t+3 issued while tile t
+// is multiplied. A K-step of the two-stage kernel cannot start before the DMA issued one step earlier has landed
+// (`__syncthreads()` waits vmcnt(0)); with L2/HBM latency of the order of a K-step's MFMA time that wait is exposed.
+// Here the wait is COUNTED — `s_waitcnt vmcnt(8)` retires tile t and leaves the 4 + 4 DMA instructions of tiles t+1
+// and t+2 in flight across a raw `s_barrier` (cdna_hip_programming.md §5 "Pipelining across barriers").
+// A tile [128][32]: 64-B rows, chunk position c' holds chunk c' ^ ((row >> 2) & 3) (conflict-free ds_read_b128 of 16
+// rows); B tile [32][128]: the 256-B-row image of b_off(). One barrier per K-step; stage (t+3) % 4 is the one every
+// wave finished reading before that barrier.
+constexpr int BK4 = 32, NST = 4;
+constexpr int A4_BYTES = BM * BK4 * 2, B4_BYTES = BK4 * BN * 2, STAGE4_BYTES = A4_BYTES + B4_BYTES;  // 8 + 8 KiB
+
+__device__ inline int a4_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
+
+template <typename T, bool IS_BF16>
+__global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
+                                                           const T* __restrict__ addend, T* __restrict__ C, int64_t M,
+                                                           int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    constexpr int EPI_BYTES = 4 * 64 * CS * 4;
+    constexpr int SMEM_BYTES = (NST * STAGE4_BYTES > EPI_BYTES) ? NST * STAGE4_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's DMA pieces per stage: A pieces wave*2, wave*2+1 (16 rows x 64 B), B pieces wave*2, wave*2+1 (4 rows x 256 B)
+    const uint16_t* a_src[2];
+    const uint16_t* b_src[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int ar = (wave * 2 + p) * 16 + (lane >> 2);
+        a_src[p] = A + (m0 + ar) * lda + (((lane & 3) ^ ((ar >> 2) & 3)) << 3);
+        const int br = (wave * 2 + p) * 4 + (lane >> 4);
+        b_src[p] = Bm + (int64_t)br * ldb + n0 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
+    }
+    auto dma = [&](int stage, int64_t k0) {
+        unsigned char* base = smem + stage * STAGE4_BYTES;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + (wave * 2 + p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
+                                             (__attribute__((address_space(3))) void*)(base + A4_BYTES + (wave * 2 + p) * 1024),
+                                             16, 0, 0);
+        }
+    };
+
+    const int a_row = wr * 64 + (lane & 15);
+    const int a_kc = lane >> 4;
+    const int b_q = (lane & 15) >> 2, b_p = lane & 3;
+    const int b_row = 8 * (lane >> 4) + b_q;
+
+    const int64_t ksteps = K / BK4;  // even: K is a multiple of 64
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem;
+
+    // Fragments of tile t+1 are read into the second register set while the MFMAs of tile t issue. The transpose reads
+    // go through inline asm: as a builtin the compiler orders them after EVERY outstanding LDS-DMA (s_waitcnt
+    // vmcnt(0)), which would undo the counted wait. Their lgkmcnt(0) carries the registers as operands so no MFMA is
+    // scheduled above it.
+    auto read_frags = [&](int64_t t, s16x8 (&af)[4], s16x4 (&blo)[4], s16x4 (&bhi)[4]) {
+        const int st = (int)(t & (NST - 1));
+        const uint32_t sA_lds = smem_lds + st * STAGE4_BYTES + a4_off(a_row, a_kc);  // rows +16 keep the swizzle term
+        const uint32_t sB_lds = smem_lds + st * STAGE4_BYTES + A4_BYTES;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(sA_lds));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(af[1]) : "v"(sA_lds));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[2]) : "v"(sA_lds));
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(af[3]) : "v"(sA_lds));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int ch = wc * 8 + ni * 2 + (b_p >> 1);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[ni]) : "v"(sB_lds + b_off(b_row, ch) + 8 * (b_p & 1)));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bhi[ni]) : "v"(sB_lds + b_off(b_row + 4, ch) + 8 * (b_p & 1)));
+        }
+    };
+    // one K-step: `cur` holds tile kt (reads issued one step earlier), `nxt` receives tile kt+1
+    auto step = [&](int64_t kt, s16x8 (&caf)[4], s16x4 (&cblo)[4], s16x4 (&cbhi)[4], s16x8 (&naf)[4], s16x4 (&nblo)[4],
+                    s16x4 (&nbhi)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(cblo[0]), "+v"(cblo[1]), "+v"(cblo[2]), "+v"(cblo[3]), "+v"(cbhi[0]), "+v"(cbhi[1]),
+                       "+v"(cbhi[2]), "+v"(cbhi[3]), "+v"(caf[0]), "+v"(caf[1]), "+v"(caf[2]), "+v"(caf[3]));
+        // tile kt+1 must have landed; tiles kt+2 and kt+3 (4 DMA instructions each) stay in flight. Past the last tile
+        // the DMA re-fetches tile ksteps-1 into a stage nobody reads again, which keeps this count (and the loop)
+        // free of branches.
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave holds tile kt in registers: its stage is free
+        const int64_t tn = kt + NST;
+        dma((int)(kt & (NST - 1)), (tn < ksteps ? tn : ksteps - 1) * BK4);
+        read_frags(kt + 1, naf, nblo, nbhi);  // past the end: a stale stage, never used
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const s16x8 bf = s16x8{cblo[ni].x, cblo[ni].y, cblo[ni].z, cblo[ni].w,
+                                       cbhi[ni].x, cbhi[ni].y, cbhi[ni].z, cbhi[ni].w};
+                acc[mi][ni] = mfma16<IS_BF16>(caf[mi], bf, acc[mi][ni]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+#pragma unroll
+    for (int t = 0; t < NST; ++t) dma(t, (int64_t)(t < ksteps ? t : ksteps - 1) * BK4);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    s16x8 af0[4], af1[4];
+    s16x4 bl0[4], bh0[4], bl1[4], bh1[4];
+    read_frags(0, af0, bl0, bh0);
+    for (int64_t kt = 0; kt < ksteps; kt += 2) {
+        step(kt, af0, bl0, bh0, af1, bl1, bh1);
+        step(kt + 1, af1, bl1, bh1, af0, bl0, bh0);
+    }
+    __syncthreads();  // every wave is done with the stages before the epilogue reuses the memory
+
+    float* ctile = reinterpret_cast<float*>(smem) + wave * (64 * CS);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ctile[(mi * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+    __builtin_amdgcn_wave_barrier();
+    const int pr = lane >> 3, pc = (lane & 7) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int rr = pass * 8 + pr;
+        const int64_t o = (m0 + wr * 64 + rr) * N + n0 + wc * 64 + pc;
+        float f[8];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        if (addend) {
+            float g[8];
+            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + o), g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] += g[i];
+        }
+        *reinterpret_cast<u32x4*>(C + o) = Elem<T>::pack(f);
+    }
+}
+
+// 256 x 256 block tile, eight waves of 128 x 64 — for problems with at least one such tile per CU. At 128 x 128 / 64 x 64
+// per wave the LDS array is as busy as the MFMA pipe (per K-step of 32 and per CU: 8 waves x 8 KiB of fragment reads at
+// 256 B/clk plus 32 KiB of DMA stores against 2 x 256 MFMA cycles per SIMD); the larger wave tile reads 12 KiB per 32
+// MFMAs instead of 8 KiB per 16 and halves the L2 -> LDS bytes per flop. Same four-stage counted-vmcnt pipeline as
+// gemm_dma4_kernel; stage = A [256][32] (a4_off image) + B [32][256] as two [32][128] half images (b_off).
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int A2_BYTES = BM2 * BK4 * 2, B2_BYTES = BK4 * BN2 * 2, STAGE2_BYTES = A2_BYTES + B2_BYTES;  // 16 + 16 KiB
+constexpr int GEMM256_SMEM = NST * STAGE2_BYTES;                                                       // 128 KiB
+constexpr int EPI2_ROWS = 32;  // rows of a wave's 128 staged per epilogue round: 8 waves x 32 x CS x 4 B = 68 KiB
+
+template <typename T, bool IS_BF16>
+__global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
+                                                             const T* __restrict__ addend, T* __restrict__ C, int64_t M,
+                                                             int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
+    unsigned char* smem = smem256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves: rows wr*128, columns wc*64
+    const int64_t m0 = (int64_t)blockIdx.y * BM2, n0 = (int64_t)blockIdx.x * BN2;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // DMA pieces of this wave per stage: A pieces 2w, 2w+1 (16 rows x 64 B); B pieces 2w, 2w+1 of 16 (half q>>3, 4 rows x 256 B)
+    const uint16_t* a_src[2];
+    const uint16_t* b_src[2];
+    int b_dst[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int ar = (wave * 2 + p) * 16 + (lane >> 2);
+        a_src[p] = A + (m0 + ar) * lda + (((lane & 3) ^ ((ar >> 2) & 3)) << 3);
+        const int q = wave * 2 + p, half = q >> 3;
+        const int br = (q & 7) * 4 + (lane >> 4);
+        b_src[p] = Bm + (int64_t)br * ldb + n0 + half * 128 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
+        b_dst[p] = A2_BYTES + half * (B2_BYTES / 2) + (q & 7) * 1024;
+    }
+    auto dma = [&](int stage, int64_t k0) {
+        unsigned char* base = smem + stage * STAGE2_BYTES;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + (wave * 2 + p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
+                                             (__attribute__((address_space(3))) void*)(base + b_dst[p]), 16, 0, 0);
+        }
+    };
+
+    const int a_row = wr * 128 + (lane & 15);
+    const int a_kc = lane >> 4;
+    const int b_q = (lane & 15) >> 2, b_p = lane & 3;
+    const int b_row = 8 * (lane >> 4) + b_q;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem;
+    const uint32_t a_rd = smem_lds + a4_off(a_row, a_kc);                      // + stage, + mi * 1024
+    const uint32_t b_rd = smem_lds + A2_BYTES + (wc >> 1) * (B2_BYTES / 2);    // + stage, + b_off(...)
+    uint32_t b_lo_off[4], b_hi_off[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int ch = (wc & 1) * 8 + ni * 2 + (b_p >> 1);
+        b_lo_off[ni] = b_rd + b_off(b_row, ch) + 8 * (b_p & 1);
+        b_hi_off[ni] = b_rd + b_off(b_row + 4, ch) + 8 * (b_p & 1);
+    }
+
+    const int64_t ksteps = K / BK4;
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) dma(t, (int64_t)(t < ksteps ? t : ksteps - 1) * BK4);
+
+    for (int64_t kt = 0; kt < ksteps; ++kt) {
+        // tile kt must have landed; tiles kt+1 and kt+2 (4 DMA instructions each) stay in flight. Past the last tile the
+        // DMA re-fetches tile ksteps-1 into a stage nobody reads again: the count and the loop stay free of branches.
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... for every wave, and every wave is done reading stage (kt-1) & 3
+        const int64_t tn = kt + NST - 1;
+        dma((int)(tn & (NST - 1)), (tn < ksteps ? tn : ksteps - 1) * BK4);
+
+        const uint32_t st = (uint32_t)(kt & (NST - 1)) * STAGE2_BYTES;
+        s16x4 blo[4], bhi[4];
+        s16x8 af[8];
+        // inline asm: as builtins the transpose reads are ordered after EVERY outstanding LDS-DMA (vmcnt(0))
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[ni]) : "v"(b_lo_off[ni] + st));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bhi[ni]) : "v"(b_hi_off[ni] + st));
+        }
+        const uint32_t aa = a_rd + st;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(af[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(af[3]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[4]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(af[5]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[6]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(af[7]) : "v"(aa));
+        // first half of the rows as soon as B and A[0..3] are back (LDS returns in order), the rest after the last read
+        asm volatile("s_waitcnt lgkmcnt(4)"
+                     : "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]),
+                       "+v"(bhi[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
+        s16x8 bf[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            bf[ni] = s16x8{blo[ni].x, blo[ni].y, blo[ni].z, blo[ni].w, bhi[ni].x, bhi[ni].y, bhi[ni].z, bhi[ni].w};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
+        __builtin_amdgcn_sched_barrier(0);  // keeps the first 16 MFMAs above the second wait
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]));
+#pragma unroll
+        for (int mi = 4; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
+    }
+    __syncthreads();  // all DMA (including the redundant tail fetches) landed, all reads done: the stages become the epilogue's
+
+    float* ctile = reinterpret_cast<float*>(smem) + wave * (EPI2_ROWS * CS);
+    const int pr = lane >> 3, pc = (lane & 7) * 8;
+#pragma unroll
+    for (int c = 0; c < 128 / EPI2_ROWS; ++c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ctile[(h * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[c * 2 + h][ni][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < EPI2_ROWS / 8; ++pass) {
+            const int rr = pass * 8 + pr;
+            const int64_t o = (m0 + wr * 128 + c * EPI2_ROWS + rr) * N + n0 + wc * 64 + pc;
+            float f[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+            if (addend) {
+                float g[8];
+                Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + o), g);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] += g[i];
+            }
+            *reinterpret_cast<u32x4*>(C + o) = Elem<T>::pack(f);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T, bool IS_BF16>
+int launch_dma256(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K,
+                  int64_t lda, int64_t ldb, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma256_kernel<T, IS_BF16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_SMEM) != hipSuccess)
+            return gnnops_check_launch("addmm attribute");
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_dma256_kernel<T, IS_BF16>), dim3((unsigned)(N / BN2), (unsigned)(M / BM2)), dim3(512),
+                       GEMM256_SMEM, stream, (const uint16_t*)mat1, (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K,
+                       lda, ldb);
+    return gnnops_check_launch("addmm");
+}
+
 // ---- fp32 operands: v_mfma_f32_16x16x4_f32 (exact fp32 products and sums, 1/16 of the bf16 MFMA rate = the fp32
 // vector peak, MI355X_MICROARCH.md "Matrix cores"). Same 128 x 128 block / 2 x 2 waves / 4 x 4 MFMA tiles; BK = 16.
 // A tile [128][16] with 20-float rows and B tile [16][128] with 144-float rows: both fragment reads (one ds_read_b32
@@ -542,7 +854,22 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
     dim3 grid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
     const bool tile_aligned = M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0 && (uintptr_t)out % 16 == 0 &&
                               (input == nullptr || (uintptr_t)input % 16 == 0);
-    const char* no_dma = getenv("GNNOPS_GEMM_NO_DMA");  // A/B switch for tools/time_gemm.py
+    const char* no_dma = getenv("GNNOPS_GEMM_NO_DMA");  // A/B switch for tools/time_gemm.py: 1 = register staging, 2 = 2-stage DMA, 3 = 4-stage 128 x 128
+    // the 256 x 256 form needs a tile per CU to fill the chip; smaller problems keep 128 x 128 tiles
+    const bool big_tiles = tile_aligned && M % BM2 == 0 && N % BN2 == 0 && (M / BM2) * (N / BN2) >= 256 &&
+                           !(no_dma && no_dma[0] != '0');
+    if (big_tiles)
+        return dtype == GNNOPS_BF16 ? launch_dma256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, K, lda, ldb, stream)
+                                    : launch_dma256<__half, false>(input, mat1, mat2, out, M, N, K, lda, ldb, stream);
+    if (tile_aligned && !(no_dma && (no_dma[0] == '1' || no_dma[0] == '2'))) {
+        if (dtype == GNNOPS_BF16)
+            hipLaunchKernelGGL((gemm_dma4_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
+                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb);
+        else
+            hipLaunchKernelGGL((gemm_dma4_kernel<__half, false>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
+                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb);
+        return gnnops_check_launch("addmm");
+    }
     if (tile_aligned && !(no_dma && no_dma[0] == '1')) {
         if (dtype == GNNOPS_BF16)
             hipLaunchKernelGGL((gemm_dma_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,

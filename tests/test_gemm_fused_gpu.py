@@ -59,6 +59,33 @@ def test_addmm_identity_layout(gnnops):
         assert torch.equal(gnnops.addmm(B.cuda(), I.cuda(), B.cuda()).cpu(), (B.float() * 2).to(torch.bfloat16)), n
 
 
+@pytest.mark.parametrize("dname", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 64), (4096, 4096, 192), (8192, 2048, 128), (2048, 8192, 320)])
+def test_addmm_big_tiles(gnnops, M, N, K, dname):
+    """>= 256 tiles of 256 x 256: the eight-wave kernel (K = 64: fewer K-steps than pipeline stages). Same bound as
+    test_addmm_matmul against a float64 product of the same 16-bit operands; plus the exact identity check."""
+    g = torch.Generator().manual_seed(5)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    B = (torch.rand(K, N, generator=g) * 2 - 1 + torch.arange(N).float().view(1, N) / N).to(TORCH_DT[dname])
+    C = (torch.rand(M, N, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    bound_acc = 4 * K * 2.0 ** -24 * (A.double().abs() @ B.double().abs())
+    prod = A.double() @ B.double()
+    for inp in (C, None):
+        got = gnnops.addmm(inp.cuda(), A.cuda(), B.cuda()) if inp is not None else gnnops.matmul(A.cuda(), B.cuda())
+        ref = prod + (inp.double() if inp is not None else 0)
+        err = (got.cpu().double() - ref).abs()
+        bound = EPS_OUT[dname] * ref.abs() + bound_acc + 1e-30
+        assert bool((err <= bound).all()), f"max err/bound {(err / bound).max().item()}"
+
+
+def test_addmm_big_tiles_identity(gnnops):
+    n = 4096
+    B = (torch.arange(n * n).view(n, n) % 251).to(torch.bfloat16)
+    I = torch.eye(n, dtype=torch.bfloat16)
+    assert torch.equal(gnnops.matmul(I.cuda(), B.cuda()).cpu(), B)
+    assert torch.equal(gnnops.matmul(B.cuda(), I.cuda()).cpu(), B)
+
+
 def test_addmm_reference_shape_fp16(gnnops):
     """The reference's first sweep length (benchmark_native_addmm.py:23-38: L = 1581, fp16): odd, unaligned rows."""
     L = 1581
