@@ -347,13 +347,17 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const uint16_t* __rest
 // (`__syncthreads()` waits vmcnt(0)); with L2/HBM latency of the order of a K-step's MFMA time that wait is exposed.
 // Here the wait is COUNTED — `s_waitcnt vmcnt(8)` retires tile t and leaves the 4 + 4 DMA instructions of tiles t+1
 // and t+2 in flight across a raw `s_barrier` (cdna_hip_programming.md §5 "Pipelining across barriers").
-// A tile [128][32]: 64-B rows, chunk position c' holds chunk c' ^ ((row >> 2) & 3) (conflict-free ds_read_b128 of 16
-// rows); B tile [32][128]: the 256-B-row image of b_off(). One barrier per K-step; stage (t+3) % 4 is the one every
+// A tile [128][32]: 64-B rows, chunk position c' holds chunk c' ^ a4_swz(row) (conflict-free ds_read_b128); B tile [32][128]: the 256-B-row image of b_off(). One barrier per K-step; stage (t+3) % 4 is the one every
 // wave finished reading before that barrier.
 constexpr int BK4 = 32, NST = 4;
 constexpr int A4_BYTES = BM * BK4 * 2, B4_BYTES = BK4 * BN * 2, STAGE4_BYTES = A4_BYTES + B4_BYTES;  // 8 + 8 KiB
 
-__device__ inline int a4_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
+// ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): with lane = row | chunk << 4 a
+// group holds chunk c of rows 0-3 and 12-15 and chunk c^1 of rows 4-11, so the four rows that share a 64-B quarter of a
+// bank row (r, r+4, r+8, r+12) need positions c^f, (c^1)^f', ...: f = 3 for rows 8-15 of every 16 makes them distinct
+// (tools/lds_conflicts.py: 4 LDS cycles per read, the conflict-free figure).
+__device__ inline int a4_swz(int row) { return ((row >> 3) & 1) * 3; }
+__device__ inline int a4_off(int row, int ch) { return row * 64 + ((ch ^ a4_swz(row)) << 4); }
 
 template <typename T, bool IS_BF16>
 __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int ar = (wave * 2 + p) * 16 + (lane >> 2);
-        a_src[p] = A + (m0 + ar) * lda + (((lane & 3) ^ ((ar >> 2) & 3)) << 3);
+        a_src[p] = A + (m0 + ar) * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
         const int br = (wave * 2 + p) * 4 + (lane >> 4);
         b_src[p] = Bm + (int64_t)br * ldb + n0 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
     }
@@ -459,6 +463,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
         step(kt, af0, bl0, bh0, af1, bl1, bh1);
         step(kt + 1, af1, bl1, bh1, af0, bl0, bh0);
     }
+    // the reads issued for the tile past the end still target live registers: retire them before anything is reused
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(bl0[0]), "+v"(bl0[1]), "+v"(bl0[2]), "+v"(bl0[3]), "+v"(bh0[0]), "+v"(bh0[1]), "+v"(bh0[2]),
+                   "+v"(bh0[3]), "+v"(af0[0]), "+v"(af0[1]), "+v"(af0[2]), "+v"(af0[3])
+                 :
+                 : "memory");
     __syncthreads();  // every wave is done with the stages before the epilogue reuses the memory
 
     float* ctile = reinterpret_cast<float*>(smem) + wave * (64 * CS);
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int ar = (wave * 2 + p) * 16 + (lane >> 2);
-        a_src[p] = A + (m0 + ar) * lda + (((lane & 3) ^ ((ar >> 2) & 3)) << 3);
+        a_src[p] = A + (m0 + ar) * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
         const int q = wave * 2 + p, half = q >> 3;
         const int br = (q & 7) * 4 + (lane >> 4);
         b_src[p] = Bm + (int64_t)br * ldb + n0 + half * 128 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
@@ -555,22 +565,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
         b_hi_off[ni] = b_rd + b_off(b_row + 4, ch) + 8 * (b_p & 1);
     }
 
-    const int64_t ksteps = K / BK4;
-#pragma unroll
-    for (int t = 0; t < NST - 1; ++t) dma(t, (int64_t)(t < ksteps ? t : ksteps - 1) * BK4);
-
-    for (int64_t kt = 0; kt < ksteps; ++kt) {
-        // tile kt must have landed; tiles kt+1 and kt+2 (4 DMA instructions each) stay in flight. Past the last tile the
-        // DMA re-fetches tile ksteps-1 into a stage nobody reads again: the count and the loop stay free of branches.
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // ... for every wave, and every wave is done reading stage (kt-1) & 3
-        const int64_t tn = kt + NST - 1;
-        dma((int)(tn & (NST - 1)), (tn < ksteps ? tn : ksteps - 1) * BK4);
-
-        const uint32_t st = (uint32_t)(kt & (NST - 1)) * STAGE2_BYTES;
-        s16x4 blo[4], bhi[4];
-        s16x8 af[8];
-        // inline asm: as builtins the transpose reads are ordered after EVERY outstanding LDS-DMA (vmcnt(0))
+    const int64_t ksteps = K / BK4;  // even: K is a multiple of 64
+    // Fragment reads are inline asm: as builtins the transpose reads are ordered after EVERY outstanding LDS-DMA
+    // (s_waitcnt vmcnt(0)), which would undo the counted waits. Each s_waitcnt carries the registers it releases as
+    // operands, so no MFMA that uses them is scheduled above it.
+    auto read_first = [&](int64_t t, s16x4 (&blo)[4], s16x4 (&bhi)[4], s16x8 (&af)[8]) {  // B and rows 0..63 of A
+        const uint32_t st = (uint32_t)(t & (NST - 1)) * STAGE2_BYTES;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[ni]) : "v"(b_lo_off[ni] + st));
@@ -581,29 +581,65 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
         asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(af[1]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[2]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(af[3]) : "v"(aa));
+    };
+    auto read_second = [&](int64_t t, s16x8 (&af)[8]) {  // rows 64..127 of A
+        const uint32_t aa = a_rd + (uint32_t)(t & (NST - 1)) * STAGE2_BYTES;
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[4]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(af[5]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[6]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(af[7]) : "v"(aa));
-        // first half of the rows as soon as B and A[0..3] are back (LDS returns in order), the rest after the last read
-        asm volatile("s_waitcnt lgkmcnt(4)"
-                     : "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]),
-                       "+v"(bhi[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
+    };
+    s16x8 af[8];
+    // One K-step, software-pipelined in halves so the LDS reads run under this wave's own MFMAs:
+    //   rows 64..127 of tile kt are read under the MFMAs of rows 0..63; B and rows 0..63 of tile kt+1 under the MFMAs of
+    //   rows 64..127. B is double-buffered in registers (cur / nxt), A reuses af[0..3] once their MFMAs have issued.
+    auto step = [&](int64_t kt, s16x4 (&cblo)[4], s16x4 (&cbhi)[4], s16x4 (&nblo)[4], s16x4 (&nbhi)[4]) {
+        read_second(kt, af);
+        asm volatile("s_waitcnt lgkmcnt(4)"  // LDS returns in order: everything but the four reads just issued
+                     : "+v"(cblo[0]), "+v"(cblo[1]), "+v"(cblo[2]), "+v"(cblo[3]), "+v"(cbhi[0]), "+v"(cbhi[1]),
+                       "+v"(cbhi[2]), "+v"(cbhi[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
         s16x8 bf[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-            bf[ni] = s16x8{blo[ni].x, blo[ni].y, blo[ni].z, blo[ni].w, bhi[ni].x, bhi[ni].y, bhi[ni].z, bhi[ni].w};
+            bf[ni] = s16x8{cblo[ni].x, cblo[ni].y, cblo[ni].z, cblo[ni].w, cbhi[ni].x, cbhi[ni].y, cbhi[ni].z, cbhi[ni].w};
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
-        __builtin_amdgcn_sched_barrier(0);  // keeps the first 16 MFMAs above the second wait
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]));
+        // tile kt+1 must have landed, tile kt+2 (4 DMA instructions) stays in flight; after the barrier every wave is
+        // done with tile kt-1's stage, which takes tile kt+3. Past the last tile the DMA re-fetches tile ksteps-1 into a
+        // stage nobody reads again: the count and the loop stay free of branches.
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int64_t tn = kt + NST - 1;
+        dma((int)(tn & (NST - 1)), (tn < ksteps ? tn : ksteps - 1) * BK4);
+        read_first(kt + 1, nblo, nbhi, af);  // past the end: a stale stage, never used
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 4; mi < 8; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) dma(t, (int64_t)(t < ksteps ? t : ksteps - 1) * BK4);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    s16x4 bl0[4], bh0[4], bl1[4], bh1[4];
+    read_first(0, bl0, bh0, af);
+    for (int64_t kt = 0; kt < ksteps; kt += 2) {
+        step(kt, bl0, bh0, bl1, bh1);
+        step(kt + 1, bl1, bh1, bl0, bh0);
     }
+    // the reads issued for the tile past the end still target live registers: retire them before anything is reused
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(bl0[0]), "+v"(bl0[1]), "+v"(bl0[2]), "+v"(bl0[3]), "+v"(bh0[0]), "+v"(bh0[1]), "+v"(bh0[2]),
+                   "+v"(bh0[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
+                 :
+                 : "memory");
     __syncthreads();  // all DMA (including the redundant tail fetches) landed, all reads done: the stages become the epilogue's
 
     float* ctile = reinterpret_cast<float*>(smem) + wave * (EPI2_ROWS * CS);
