@@ -10,12 +10,13 @@
 //   B tile [64][128] stays ROW-major in LDS (coalesced 16-B global loads, no transposing writes) in the
 //     guide's swizzled 256-B-row image; the k-strided B fragment comes from two ds_read_b64_tr_b16
 //     hardware-transpose reads (4 k-rows x 16 columns per 16-lane group each).
-//   4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles (64 accumulator VGPRs). Two LDS stages: the next tile is
-//     loaded to registers before, and stored to the other stage after, the 32 MFMAs of the current one — one
-//     barrier per K-step. The epilogue parks each wave's fp32 tile in LDS and writes 16-B row pieces.
-// Still a register-staged pipeline (~0.3 of the MFMA roof); LDS-DMA staging with counted waits is the follow-up. Operands whose row length is not a multiple of
-// 8 elements (the reference sweeps L = 1581 ... 8164) are first copied into 16-B aligned, zero-padded rows
-// (pad_rows_kernel, workspace), so the staging loads are always 16-B vectors.
+//   4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles (64 accumulator VGPRs). The epilogue parks each wave's fp32
+//     tile in LDS and writes 16-B row pieces.
+// Three kernels (gemm_plan() picks): the register-staged, fully bounds-checked gemm_kernel for small problems; and for
+// anything of size the LDS-DMA pipelines gemm_dma4_kernel (128 x 128 tiles) and gemm_dma256_kernel (256 x 256, eight
+// waves) — global_load_lds_dwordx4 into four LDS stages of K = 32 with counted vmcnt waits. Operands whose rows are not
+// 16-B aligned, or whose K is not a whole number of K-tiles (the reference sweeps L = 1581 ... 8164), are first copied
+// into aligned, zero-padded rows (pad_rows_kernel, workspace).
 #include "common.h"
 #include <stdlib.h>
 
@@ -46,6 +47,49 @@ __device__ inline f32x4 mfma16(const s16x8& a, const s16x8& b, const f32x4& c) {
 // ds_read_b64_tr_b16.
 __device__ inline int a_off(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
 __device__ inline int b_off(int row, int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+// Eight consecutive outputs of one row, columns col..col+7: += addend, one rounding, stored as wide as the row
+// alignment allows (16 B when N % 8 == 0, 8 B when N % 4 == 0, else per element); rows >= M and columns >= N are dropped.
+template <typename T>
+__device__ inline void epi_store8(T* __restrict__ C, const T* __restrict__ addend, int64_t row, int64_t col, int64_t M,
+                                  int64_t N, float (&f)[8], bool vec_c, bool half_c) {
+    if (row >= M || col >= N) return;
+    if (vec_c && col + 8 <= N) {
+        if (addend) {
+            float g[8];
+            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + row * N + col), g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] += g[i];
+        }
+        *reinterpret_cast<u32x4*>(C + row * N + col) = Elem<T>::pack(f);
+    } else if (half_c) {  // rows 8-B aligned (N % 4 == 0): two 4-element pieces, each whole or absent
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (col + 4 * h < N) {
+                float* fh = f + 4 * h;
+                if (addend) {
+                    const uint2 g2 = *reinterpret_cast<const uint2*>(addend + row * N + col + 4 * h);
+                    float g[8];
+                    Elem<T>::unpack(u32x4{g2.x, g2.y, 0u, 0u}, g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fh[i] += g[i];
+                }
+                float tmp[8] = {fh[0], fh[1], fh[2], fh[3], 0.f, 0.f, 0.f, 0.f};
+                const u32x4 pk = Elem<T>::pack(tmp);
+                *reinterpret_cast<uint2*>(C + row * N + col + 4 * h) = uint2{pk.x, pk.y};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (col + i < N) {
+                float v = f[i];
+                if (addend) v += Elem<T>::load(addend + row * N + col + i);
+                Elem<T>::store(C + row * N + col + i, v);
+            }
+        }
+    }
+}
 
 // 8 consecutive 16-bit elements of row `r`, columns c..c+7 of a [rows][cols] row-major matrix whose rows start
 // ALIGN-byte aligned (cols * 2 % ALIGN == 0): ALIGN = 16 -> one dwordx4, 8 -> two dwordx2, 4 -> four dwords.
@@ -180,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint16_t* __restrict
                 ctile[(mi * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[mi][ni][r];
     __builtin_amdgcn_wave_barrier();  // the tile is private to this wave; LDS ops of one wave complete in order
     const bool vec_c = (N % 8 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
+    const bool half_c = (N % 4 == 0) && ((uintptr_t)C % 8 == 0) && (addend == nullptr || (uintptr_t)addend % 8 == 0);
     const int pr = lane >> 3, pc = (lane & 7) * 8;
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
@@ -190,165 +235,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint16_t* __restrict
         const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
         f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        if (row >= M || col >= N) continue;
-        const bool half_c = (N % 4 == 0) && ((uintptr_t)C % 8 == 0) && (addend == nullptr || (uintptr_t)addend % 8 == 0);
-        if (vec_c && col + 8 <= N) {
-            if (addend) {
-                float g[8];
-                Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + row * N + col), g);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) f[i] += g[i];
-            }
-            *reinterpret_cast<u32x4*>(C + row * N + col) = Elem<T>::pack(f);
-        } else if (half_c) {  // rows 8-B aligned (N % 4 == 0): two 4-element pieces, each whole or absent
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (col + 4 * h < N) {
-                    float* fh = f + 4 * h;
-                    if (addend) {
-                        const uint2 g2 = *reinterpret_cast<const uint2*>(addend + row * N + col + 4 * h);
-                        float g[8];
-                        Elem<T>::unpack(u32x4{g2.x, g2.y, 0u, 0u}, g);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) fh[i] += g[i];
-                    }
-                    float tmp[8] = {fh[0], fh[1], fh[2], fh[3], 0.f, 0.f, 0.f, 0.f};
-                    const u32x4 pk = Elem<T>::pack(tmp);
-                    *reinterpret_cast<uint2*>(C + row * N + col + 4 * h) = uint2{pk.x, pk.y};
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (col + i < N) {
-                    float v = f[i];
-                    if (addend) v += Elem<T>::load(addend + row * N + col + i);
-                    Elem<T>::store(C + row * N + col + i, v);
-                }
-            }
-        }
+        epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c);
     }
 }
 
-// Copy a [rows][cols] 16-bit matrix into rows of `ld` elements (ld % 8 == 0), zero-filling the tail, so that every
-// row starts 16-B aligned and the GEMM's 16-B staging loads apply (the reference sweeps odd sizes: L = 1581...).
-// Fast path for tile-aligned problems (M % 128 == 0, N % 128 == 0, K % 64 == 0): the same tiles, swizzled images,
-// fragment reads and epilogue, but the staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction written
-// straight into LDS, the swizzle applied on the per-lane SOURCE address), so no staging VGPRs and no ds_write pass.
-// The DMA of tile t+1 is issued before the 32 MFMAs of tile t and retired by the barrier that ends the step.
-template <typename T, bool IS_BF16>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
-                                                          const T* __restrict__ addend, T* __restrict__ C, int64_t M,
-                                                          int64_t N, int64_t K, int64_t lda, int64_t ldb) {
-    constexpr int EPI_BYTES = 4 * 64 * CS * 4;
-    constexpr int SMEM_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // DMA pieces of this wave: A pieces wave*4 .. +3 (8 rows x 128 B each), B pieces wave*4 .. +3 (4 rows x 256 B each).
-    // Lane i lands at byte 16*i of the piece, i.e. (row, position c'); it must fetch global chunk c = c' ^ swizzle(row).
-    const uint16_t* a_src[4];
-    const uint16_t* b_src[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int ar = (wave * 4 + p) * 8 + (lane >> 3);
-        a_src[p] = A + (m0 + ar) * lda + (((lane & 7) ^ (ar & 7)) << 3);
-        const int br = (wave * 4 + p) * 4 + (lane >> 4);
-        b_src[p] = Bm + (int64_t)br * ldb + n0 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
-    }
-    auto dma = [&](int stage, int64_t k0) {
-        unsigned char* base = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
-                                             (__attribute__((address_space(3))) void*)(base + (wave * 4 + p) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
-                                             (__attribute__((address_space(3))) void*)(base + A_TILE_BYTES + (wave * 4 + p) * 1024),
-                                             16, 0, 0);
-        }
-    };
-
-    const int a_row = wr * 64 + (lane & 15);
-    const int a_kc = lane >> 4;
-    const int b_q = (lane & 15) >> 2, b_p = lane & 3;
-    const int b_row = 8 * (lane >> 4) + b_q;
-
-    const int64_t ksteps = K / BK;
-    dma(0, 0);
-    __syncthreads();
-    for (int64_t kt = 0; kt < ksteps; ++kt) {
-        const int cur = (int)(kt & 1);
-        if (kt + 1 < ksteps) dma(cur ^ 1, (kt + 1) * BK);
-        const unsigned char* sA = smem + cur * STAGE_BYTES;
-        const unsigned char* sB = sA + A_TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            s16x8 af[4], bf[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                af[mi] = *reinterpret_cast<const s16x8*>(sA + a_off(a_row + mi * 16, ks * 4 + a_kc));
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int ch = wc * 8 + ni * 2 + (b_p >> 1);
-                const int r_lo = ks * 32 + b_row;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(sB + b_off(r_lo, ch) + 8 * (b_p & 1)));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(sB + b_off(r_lo + 4, ch) + 8 * (b_p & 1)));
-                bf[ni] = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
-        }
-        __syncthreads();  // retires this wave's DMA (vmcnt(0)) and everybody's reads of `cur`
-    }
-
-    float* ctile = reinterpret_cast<float*>(smem) + wave * (64 * CS);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ctile[(mi * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[mi][ni][r];
-    __builtin_amdgcn_wave_barrier();
-    const int pr = lane >> 3, pc = (lane & 7) * 8;
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const int rr = pass * 8 + pr;
-        const int64_t o = (m0 + wr * 64 + rr) * N + n0 + wc * 64 + pc;
-        float f[8];
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
-        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        if (addend) {
-            float g[8];
-            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + o), g);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] += g[i];
-        }
-        *reinterpret_cast<u32x4*>(C + o) = Elem<T>::pack(f);
-    }
-}
-
-// Deeper pipeline for tile-aligned problems: BK = 32 and FOUR LDS stages, the LDS-DMA of tile t+3 issued while tile t
-// is multiplied. A K-step of the two-stage kernel cannot start before the DMA issued one step earlier has landed
-// (`__syncthreads()` waits vmcnt(0)); with L2/HBM latency of the order of a K-step's MFMA time that wait is exposed.
-// Here the wait is COUNTED — `s_waitcnt vmcnt(8)` retires tile t and leaves the 4 + 4 DMA instructions of tiles t+1
-// and t+2 in flight across a raw `s_barrier` (cdna_hip_programming.md §5 "Pipelining across barriers").
-// A tile [128][32]: 64-B rows, chunk position c' holds chunk c' ^ a4_swz(row) (conflict-free ds_read_b128); B tile [32][128]: the 256-B-row image of b_off(). One barrier per K-step; stage (t+3) % 4 is the one every
-// wave finished reading before that barrier.
+// LDS-DMA pipeline: BK = 32 and FOUR LDS stages, staged by global_load_lds_dwordx4 (1 KiB per wave-instruction written
+// straight into LDS, the swizzle applied on the per-lane SOURCE address: no staging VGPRs, no ds_write pass), the DMA of
+// tile t+3 issued while tile t is multiplied. With two stages and `__syncthreads()` (which waits vmcnt(0)) a K-step
+// cannot start before the DMA issued one step earlier has landed, and L2/HBM latency is of the order of a K-step's MFMA
+// time (measured: 860 TFLOP/s at 8192^3 bf16, against 1000 here). The wait is COUNTED — `s_waitcnt vmcnt(8)` retires
+// tile t and leaves the 4 + 4 DMA instructions of tiles t+1 and t+2 in flight across a raw `s_barrier`
+// (cdna_hip_programming.md §5 "Pipelining across barriers").
+// A tile [128][32]: 64-B rows, chunk position c' holds chunk c' ^ a4_swz(row) (conflict-free ds_read_b128); B tile
+// [32][128]: the 256-B-row image of b_off(). One barrier per K-step; stage (t+3) % 4 is the one every wave finished
+// reading before that barrier.
 constexpr int BK4 = 32, NST = 4;
 constexpr int A4_BYTES = BM * BK4 * 2, B4_BYTES = BK4 * BN * 2, STAGE4_BYTES = A4_BYTES + B4_BYTES;  // 8 + 8 KiB
 
@@ -382,10 +282,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
     const uint16_t* b_src[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
+        // rows past M re-read row M-1 and column chunks past ldb re-read the last chunk: in-bounds filler for outputs
+        // the epilogue drops (the host pads K, never M or N)
         const int ar = (wave * 2 + p) * 16 + (lane >> 2);
-        a_src[p] = A + (m0 + ar) * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
+        const int64_t arow = (m0 + ar < M) ? m0 + ar : M - 1;
+        a_src[p] = A + arow * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
         const int br = (wave * 2 + p) * 4 + (lane >> 4);
-        b_src[p] = Bm + (int64_t)br * ldb + n0 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
+        int64_t bcol = n0 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
+        if (bcol > ldb - 8) bcol = ldb - 8;
+        b_src[p] = Bm + (int64_t)br * ldb + bcol;
     }
     auto dma = [&](int stage, int64_t k0) {
         unsigned char* base = smem + stage * STAGE4_BYTES;
@@ -480,22 +385,17 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
             for (int r = 0; r < 4; ++r)
                 ctile[(mi * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[mi][ni][r];
     __builtin_amdgcn_wave_barrier();
+    const bool vec_c = (N % 8 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
+    const bool half_c = (N % 4 == 0) && ((uintptr_t)C % 8 == 0) && (addend == nullptr || (uintptr_t)addend % 8 == 0);
     const int pr = lane >> 3, pc = (lane & 7) * 8;
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int rr = pass * 8 + pr;
-        const int64_t o = (m0 + wr * 64 + rr) * N + n0 + wc * 64 + pc;
         float f[8];
         const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
         f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        if (addend) {
-            float g[8];
-            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + o), g);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] += g[i];
-        }
-        *reinterpret_cast<u32x4*>(C + o) = Elem<T>::pack(f);
+        epi_store8<T>(C, addend, m0 + wr * 64 + rr, n0 + wc * 64 + pc, M, N, f, vec_c, half_c);
     }
 }
 
@@ -533,10 +433,13 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int ar = (wave * 2 + p) * 16 + (lane >> 2);
-        a_src[p] = A + (m0 + ar) * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
+        const int64_t arow = (m0 + ar < M) ? m0 + ar : M - 1;  // in-bounds filler, as in gemm_dma4_kernel
+        a_src[p] = A + arow * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
         const int q = wave * 2 + p, half = q >> 3;
         const int br = (q & 7) * 4 + (lane >> 4);
-        b_src[p] = Bm + (int64_t)br * ldb + n0 + half * 128 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
+        int64_t bcol = n0 + half * 128 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
+        if (bcol > ldb - 8) bcol = ldb - 8;
+        b_src[p] = Bm + (int64_t)br * ldb + bcol;
         b_dst[p] = A2_BYTES + half * (B2_BYTES / 2) + (q & 7) * 1024;
     }
     auto dma = [&](int stage, int64_t k0) {
@@ -643,6 +546,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
     __syncthreads();  // all DMA (including the redundant tail fetches) landed, all reads done: the stages become the epilogue's
 
     float* ctile = reinterpret_cast<float*>(smem) + wave * (EPI2_ROWS * CS);
+    const bool vec_c = (N % 8 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
+    const bool half_c = (N % 4 == 0) && ((uintptr_t)C % 8 == 0) && (addend == nullptr || (uintptr_t)addend % 8 == 0);
     const int pr = lane >> 3, pc = (lane & 7) * 8;
 #pragma unroll
     for (int c = 0; c < 128 / EPI2_ROWS; ++c) {
@@ -657,18 +562,11 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
 #pragma unroll
         for (int pass = 0; pass < EPI2_ROWS / 8; ++pass) {
             const int rr = pass * 8 + pr;
-            const int64_t o = (m0 + wr * 128 + c * EPI2_ROWS + rr) * N + n0 + wc * 64 + pc;
             float f[8];
             const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
             f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-            if (addend) {
-                float g[8];
-                Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + o), g);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) f[i] += g[i];
-            }
-            *reinterpret_cast<u32x4*>(C + o) = Elem<T>::pack(f);
+            epi_store8<T>(C, addend, m0 + wr * 128 + c * EPI2_ROWS + rr, n0 + wc * 64 + pc, M, N, f, vec_c, half_c);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -684,7 +582,7 @@ int launch_dma256(const void* input, const void* mat1, const void* mat2, void* o
             return gnnops_check_launch("addmm attribute");
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_dma256_kernel<T, IS_BF16>), dim3((unsigned)(N / BN2), (unsigned)(M / BM2)), dim3(512),
+    hipLaunchKernelGGL((gemm_dma256_kernel<T, IS_BF16>), dim3((unsigned)gnnops_cdiv(N, BN2), (unsigned)gnnops_cdiv(M, BM2)), dim3(512),
                        GEMM256_SMEM, stream, (const uint16_t*)mat1, (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K,
                        lda, ldb);
     return gnnops_check_launch("addmm");
@@ -808,8 +706,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 
 template <int ALIGN>
 __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t cols,
-                                int64_t ld) {
-    const int64_t chunks = ld / 8, total = rows * chunks;  // one 16-B output chunk per thread
+                                int64_t ld, int64_t rows_out) {
+    const int64_t chunks = ld / 8, total = rows_out * chunks;  // one 16-B output chunk per thread; rows >= `rows` are zero
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / chunks, c = (i % chunks) * 8;
         u32x4 v;
@@ -819,7 +717,7 @@ __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __res
             const uint16_t* p = in + r * cols + c;
             uint16_t e[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = (c + j < cols) ? p[j] : (uint16_t)0;
+            for (int j = 0; j < 8; ++j) e[j] = (r < rows && c + j < cols) ? p[j] : (uint16_t)0;
             v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
             v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
         }
@@ -827,29 +725,66 @@ __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __res
     }
 }
 
-inline void launch_pad(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld, hipStream_t stream) {
-    const dim3 grid(gnnops_grid_cap(gnnops_cdiv(rows * ld / 8, 256), 256 * 16));
+inline void launch_pad(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld, int64_t rows_out, hipStream_t stream) {
+    const dim3 grid(gnnops_grid_cap(gnnops_cdiv(rows_out * ld / 8, 256), 256 * 16));
     const uint16_t* i = (const uint16_t*)in;
     uint16_t* o = (uint16_t*)out;
     if (cols % 4 == 0 && (uintptr_t)in % 8 == 0)
-        hipLaunchKernelGGL(pad_rows_kernel<8>, grid, dim3(256), 0, stream, i, o, rows, cols, ld);
+        hipLaunchKernelGGL(pad_rows_kernel<8>, grid, dim3(256), 0, stream, i, o, rows, cols, ld, rows_out);
     else if (cols % 2 == 0 && (uintptr_t)in % 4 == 0)
-        hipLaunchKernelGGL(pad_rows_kernel<4>, grid, dim3(256), 0, stream, i, o, rows, cols, ld);
+        hipLaunchKernelGGL(pad_rows_kernel<4>, grid, dim3(256), 0, stream, i, o, rows, cols, ld, rows_out);
     else
-        hipLaunchKernelGGL(pad_rows_kernel<2>, grid, dim3(256), 0, stream, i, o, rows, cols, ld);
+        hipLaunchKernelGGL(pad_rows_kernel<2>, grid, dim3(256), 0, stream, i, o, rows, cols, ld, rows_out);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-inline int64_t round8(int64_t v) { return (v + 7) / 8 * 8; }
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// How a 16-bit problem is run. The LDS-DMA kernels take any M and N (filler rows / columns, guarded epilogue) but whole
+// K-tiles of 64 with zeros past K on BOTH operands (0 x Inf would poison valid outputs), and 16-B aligned rows; the
+// register-staged kernel bounds-checks everything and only needs the 16-B aligned rows. Operands that do not comply
+// are copied into the workspace with zero fill (pad_rows_kernel) — the reference sweeps odd sizes (L = 1581 ... 8164),
+// for which the copies cost ~10 % of the product and the DMA kernels gain more than that.
+struct GemmPlan {
+    int path;             // 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 2 LDS-DMA 256 x 256
+    int64_t Kp, lda, ldb; // K as the kernel sees it, row lengths of the operands as the kernel sees them
+    bool copy_a, copy_b;
+    size_t a_bytes, b_bytes;
+};
+
+inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
+    GemmPlan g{};
+    const char* sw = getenv("GNNOPS_GEMM_NO_DMA");  // A/B switch for tools/time_gemm.py: 1 = register staging, 3 = 128 x 128 DMA only
+    const bool aligned = M % BM == 0 && N % BN == 0 && K % BK == 0;
+    const bool dma = K > 0 && !(sw && sw[0] == '1') && (aligned || (M >= 512 && N >= 512 && K >= 256));
+    if (dma) {
+        g.path = (gnnops_cdiv(M, BM2) * gnnops_cdiv(N, BN2) >= 256 && !(sw && sw[0] == '3')) ? 2 : 1;
+        g.Kp = round_up(K, 64);
+        g.copy_a = K % 64 != 0;
+        g.copy_b = K % 64 != 0 || N % 8 != 0;
+        g.lda = g.Kp;
+        g.ldb = round_up(N, 8);
+        g.a_bytes = g.copy_a ? align_up((size_t)M * g.lda * 2, 256) : 0;
+        g.b_bytes = g.copy_b ? align_up((size_t)g.Kp * g.ldb * 2, 256) : 0;
+    } else {
+        g.path = 0;
+        g.Kp = K;
+        g.copy_a = K % 8 != 0 && K > 0;
+        g.copy_b = N % 8 != 0 && K > 0;
+        g.lda = round_up(K, 8);
+        g.ldb = round_up(N, 8);
+        g.a_bytes = g.copy_a ? align_up((size_t)M * g.lda * 2, 256) : 0;
+        g.b_bytes = g.copy_b ? align_up((size_t)K * g.ldb * 2, 256) : 0;
+    }
+    return g;
+}
 
 }  // namespace
 
 extern "C" size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M < 0 || N < 0 || K < 0) return 0;
-    size_t b = 0;
-    if (K % 8) b += align_up((size_t)M * round8(K) * 2, 256);   // 16-bit operands only; fp32 needs none
-    if (N % 8) b += align_up((size_t)K * round8(N) * 2, 256);
-    return b;
+    const GemmPlan g = gemm_plan(M, N, K);  // 16-bit operands only; fp32 needs none
+    return g.a_bytes + g.b_bytes;
 }
 
 extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N,
@@ -869,50 +804,37 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
                            (const float*)input, (float*)out, M, N, K, a_vec, b_vec);
         return gnnops_check_launch("addmm f32");
     }
-    const size_t need = gnnops_addmm_workspace_bytes(M, N, K);
+    const GemmPlan g = gemm_plan(M, N, K);
+    const size_t need = g.a_bytes + g.b_bytes;
     GNNOPS_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), GNNOPS_EWORKSPACE, "addmm: workspace %zu < %zu",
                    workspace_bytes, need);
     int64_t lda = K, ldb = N;
     char* w = (char*)workspace;
-    if (K % 8 && K > 0) {
-        lda = round8(K);
-        launch_pad(mat1, w, M, K, lda, stream);
+    if (g.copy_a) {
+        lda = g.lda;
+        launch_pad(mat1, w, M, K, lda, M, stream);
         mat1 = w;
-        w += align_up((size_t)M * lda * 2, 256);
+        w += g.a_bytes;
     }
-    if (N % 8 && K > 0) {
-        ldb = round8(N);
-        launch_pad(mat2, w, K, N, ldb, stream);
+    if (g.copy_b) {
+        ldb = g.ldb;
+        launch_pad(mat2, w, K, N, ldb, g.Kp, stream);  // rows K .. Kp-1 zero
         mat2 = w;
     }
     GNNOPS_REQUIRE(K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0), GNNOPS_EUNSUPPORTED,
                    "addmm: operand base pointers must be 16-byte aligned");
+    if (g.path == 2)
+        return dtype == GNNOPS_BF16
+                   ? launch_dma256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, stream)
+                   : launch_dma256<__half, false>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, stream);
     dim3 grid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
-    const bool tile_aligned = M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0 && (uintptr_t)out % 16 == 0 &&
-                              (input == nullptr || (uintptr_t)input % 16 == 0);
-    const char* no_dma = getenv("GNNOPS_GEMM_NO_DMA");  // A/B switch for tools/time_gemm.py: 1 = register staging, 2 = 2-stage DMA, 3 = 4-stage 128 x 128
-    // the 256 x 256 form needs a tile per CU to fill the chip; smaller problems keep 128 x 128 tiles
-    const bool big_tiles = tile_aligned && M % BM2 == 0 && N % BN2 == 0 && (M / BM2) * (N / BN2) >= 256 &&
-                           !(no_dma && no_dma[0] != '0');
-    if (big_tiles)
-        return dtype == GNNOPS_BF16 ? launch_dma256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, K, lda, ldb, stream)
-                                    : launch_dma256<__half, false>(input, mat1, mat2, out, M, N, K, lda, ldb, stream);
-    if (tile_aligned && !(no_dma && (no_dma[0] == '1' || no_dma[0] == '2'))) {
+    if (g.path == 1) {
         if (dtype == GNNOPS_BF16)
             hipLaunchKernelGGL((gemm_dma4_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb);
+                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, g.Kp, lda, ldb);
         else
             hipLaunchKernelGGL((gemm_dma4_kernel<__half, false>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb);
-        return gnnops_check_launch("addmm");
-    }
-    if (tile_aligned && !(no_dma && no_dma[0] == '1')) {
-        if (dtype == GNNOPS_BF16)
-            hipLaunchKernelGGL((gemm_dma_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb);
-        else
-            hipLaunchKernelGGL((gemm_dma_kernel<__half, false>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb);
+                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, g.Kp, lda, ldb);
         return gnnops_check_launch("addmm");
     }
     if (dtype == GNNOPS_BF16)

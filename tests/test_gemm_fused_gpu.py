@@ -60,10 +60,13 @@ def test_addmm_identity_layout(gnnops):
 
 
 @pytest.mark.parametrize("dname", ["bf16", "f16"])
-@pytest.mark.parametrize("M,N,K", [(4096, 4096, 64), (4096, 4096, 192), (8192, 2048, 128), (2048, 8192, 320)])
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 64), (4096, 4096, 192), (8192, 2048, 128), (2048, 8192, 320),
+                                   (4099, 4101, 300), (4090, 4092, 263), (1581, 1581, 1581), (700, 900, 257), (513, 520, 512)])
 def test_addmm_big_tiles(gnnops, M, N, K, dname):
-    """>= 256 tiles of 256 x 256: the eight-wave kernel (K = 64: fewer K-steps than pipeline stages). Same bound as
-    test_addmm_matmul against a float64 product of the same 16-bit operands; plus the exact identity check."""
+    """The LDS-DMA kernels: >= 256 tiles of 256 x 256 take the eight-wave kernel (K = 64: fewer K-steps than pipeline
+    stages), smaller grids the 128 x 128 one; odd M / N / K exercise the filler rows, the zero-padded K tail and the
+    8-B / per-element epilogue stores. Same bound as test_addmm_matmul against a float64 product of the same 16-bit
+    operands."""
     g = torch.Generator().manual_seed(5)
     A = (torch.rand(M, K, generator=g) * 2 - 1).to(TORCH_DT[dname])
     B = (torch.rand(K, N, generator=g) * 2 - 1 + torch.arange(N).float().view(1, N) / N).to(TORCH_DT[dname])
