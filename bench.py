@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cut", type=float, default=0.1,
+                    help="N>1 only: fraction of each rank's edges whose destination another rank owns (edge cut of the "
+                         "partition; the rest fall uniformly in the rank's own rows). (G-1)/G = unpartitioned uniform graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-ops", action="store_true", help="skip the per-op table (scatter_min/max/mean, index_select, index_add_)")
     args = ap.parse_args()
@@ -86,15 +89,29 @@ def main():
     Ntot = Nloc * world
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
     src = torch.rand(E, D, generator=gen, device=dev, dtype=torch.float32)
-    index = torch.randint(0, Ntot, (E,), generator=gen, device=dev, dtype=torch.int64)
+
+    def make_index(cut):
+        """Global destination ids of this rank's E edges: a fraction `cut` uniform over the OTHER ranks' rows, the rest
+        uniform over this rank's own rows [rank*Nloc, (rank+1)*Nloc) — a partitioned graph with that edge cut."""
+        lo = rank * Nloc
+        own = torch.randint(lo, lo + Nloc, (E,), generator=gen, device=dev, dtype=torch.int64)
+        if world == 1 or cut <= 0:
+            return own
+        other = torch.randint(0, Ntot - Nloc, (E,), generator=gen, device=dev, dtype=torch.int64)
+        other += (other >= lo).to(torch.int64) * Nloc
+        cross = torch.rand(E, generator=gen, device=dev) < cut
+        return torch.where(cross, other, own)
+
+    index = make_index(args.cut)
     slab = torch.empty(Nloc, D, device=dev, dtype=torch.float32) if dist is not None else None
+    exchange = "sparse"
 
     def step():
         if dist is None:
             return gnnops.scatter_add(src, index, dim=0, dim_size=Ntot)
         from gnnops.dist import sharded_scatter
 
-        return sharded_scatter(src, index, Ntot, "sum", out_slab=slab)
+        return sharded_scatter(src, index, Ntot, "sum", out_slab=slab, exchange=exchange)
 
     def fence():
         if dist is not None:
@@ -129,37 +146,56 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (uniform random src, uniform random unsorted int64 row index, device RNG seed 42)",
+        "data": "synthetic (uniform random src, uniform random unsorted int64 row index, device RNG seed 42)" + (
+            "" if world == 1 else f"; partitioned graph: {args.cut:.3f} of every rank's edges cross to rows of other ranks"),
         "config": {
             "workload": f"{args.workload}: torch_scatter.scatter_add(src[E,D], index[E], dim=0, dim_size=N), "
                         f"N={Ntot} E={E * world} D={D} fp32, layout R" + ("" if world == 1 else
-                        f"; per GPU E={E}, owned rows={Nloc}, one RCCL reduce-scatter of the [N,D] partials"),
+                        f"; per GPU E={E}, owned rows={Nloc}, edge cut {args.cut:.3f}, one sparse reduce-scatter "
+                        f"(all-to-all-v of per-destination partial rows over RCCL)"),
             "algorithmic_GB_per_step": round(job_bytes / 1e9, 3),
             "pct_of_hbm_peak": round(100 * value / (HBM_PEAK_GBS * world), 2),
         },
     }
 
     if dist is not None:
-        # Same per-GPU work with DESTINATION-partitioned edges (every rank holds only edges whose destination it owns):
-        # the exchange disappears and the path is G replicas of config 2 — reported beside the headline, never as it.
-        own = torch.randint(0, Nloc, (E,), generator=gen, device=dev, dtype=torch.int64)
-        for _ in range(max(args.warmup, 1)):
-            o2 = gnnops.scatter_add(src, own, dim=0, dim_size=Nloc)
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            o2 = gnnops.scatter_add(src, own, dim=0, dim_size=Nloc)
-        fence()
-        el2 = time.perf_counter() - t1
-        t = torch.tensor([el2], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el2 = float(t.item())
-        del o2, own
-        result["dst_partitioned_no_exchange"] = {
-            "value": round(job_bytes / (el2 / args.steps) / 1e9, 1), "unit": "GB/s",
-            "ms_per_step": round(el2 / args.steps * 1e3, 4),
-            "note": "edges pre-bucketed by destination owner: local plan build + segment reduce only, no collective",
+        def timed_variant(idx, exch, steps, warm=1):
+            nonlocal index, exchange
+            keep = (index, exchange)
+            index, exchange = idx, exch
+            try:
+                for _ in range(warm):
+                    step()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                fence()
+                el = time.perf_counter() - t1
+            finally:
+                index, exchange = keep
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item()) / steps
+            return {"value": round(job_bytes / el / 1e9, 1), "unit": "GB/s", "ms_per_step": round(el * 1e3, 4)}
+
+        few = max(1, min(args.steps, 3))
+        # The same per-GPU work on graphs with other edge cuts, beside the headline, never as it:
+        #   cut 0           edges pre-bucketed by destination owner (BASELINE config 5 read literally): nothing to exchange
+        #   cut (G-1)/G     an UNPARTITIONED uniform random graph: nearly every edge crosses; sparse and dense exchange
+        result["other_cuts"] = {
+            "cut_0": dict(timed_variant(make_index(0.0), "sparse", few), note="destination-partitioned edges: empty exchange"),
         }
+        if world > 1:
+            uni = make_index((world - 1) / world)
+            result["other_cuts"]["uniform_random_graph"] = {
+                "cut": round((world - 1) / world, 4),
+                "sparse_exchange": timed_variant(uni, "sparse", few),
+                "dense_reduce_scatter": timed_variant(uni, "dense", few),
+                "note": "xGMI-bound: bytes on the wire per rank ~ distinct remote destinations x 520 B (sparse) or "
+                        "(G-1)/G x N x 512 B (dense)",
+            }
+            del uni
 
     if rank == 0 and world == 1:
         result["roofline"] = roofline_leg(torch, gnnops, lib, src, index, Ntot, E, D, args.steps, args.workload == "c2")

@@ -2,20 +2,34 @@
 
 One process per GPU. Edges are partitioned by position (rank g holds src_g [E_g, D] and index_g [E_g]
 with GLOBAL destination ids anywhere in [0, n_total)); destination rows are partitioned contiguously
-(rank g owns rows [g*n_total/G, (g+1)*n_total/G)). The path has exactly one exchange step:
+(rank g owns rows [g*n_total/G, (g+1)*n_total/G)). The path has exactly one exchange step, and two forms of it:
 
-  1. local segment reduce into a partial [n_total, D] buffer (our kernels, rows grouped by owner),
-  2. ONE reduce-scatter (RCCL over xGMI; `torch.distributed` backend "nccl" is RCCL on ROCm) that
-     leaves each rank with the summed slab it owns.
+``exchange="sparse"`` (default) — a reduce-scatter of only what is there:
+  1. one plan (stable inverted index) over this rank's edges;
+  2. edges whose destination another rank owns are reduced per DISTINCT destination into compact
+     (id, row) lists, grouped by owner (ids ascend, so the groups are contiguous slices);
+  3. ONE all-to-all-v of those lists (RCCL over xGMI; `torch.distributed` backend "nccl" is RCCL on ROCm) —
+     issued asynchronously, while
+  4. the edges this rank owns itself are reduced straight into its slab;
+  5. the received rows are scatter-reduced into the slab.
+  Bytes on the wire per rank = (#distinct remote destinations touched) x (row + 8), i.e. proportional to the
+  edge cut of the partition, not to n_total. RCCL has no sparse reduce-scatter; this composes one from
+  all_to_all_single and the local segment reduce.
+
+``exchange="dense"`` — local scatter into a partial [n_total, D] buffer, then ONE `reduce_scatter_tensor`.
+  Bytes on the wire per rank = (G-1)/G x n_total x row whatever the cut; kept for comparison and for
+  graphs so dense that every rank touches every destination.
 
 The reference has no distributed code; this module is the MI355X design for config 5.
-`local_scatter` is injectable so the exchange logic is testable on CPU with the gloo backend (tests
-pass the oracle there); the product default is the HIP op and refuses CPU tensors like everything else.
+The local pieces are injectable (`local=` / `local_scatter=`) so the exchange logic is testable on CPU with the
+gloo backend (tests pass numpy/oracle stand-ins there); the product default is the HIP path and refuses CPU
+tensors like everything else.
 """
 import torch
 import torch.distributed as dist
 
 _REDUCE_OP = {"sum": dist.ReduceOp.SUM, "add": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}
+_SPARSE_REDUCES = ("sum", "add", "min", "max", "mul")
 
 
 def owned_rows(n_total, rank, world):
@@ -26,24 +40,154 @@ def owned_rows(n_total, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, local_scatter=None, out_slab=None):
+class HipLocal:
+    """The local (per-GPU) pieces of the sparse exchange, on our kernels: plan build + segment reduce."""
+
+    def split(self, src, index, n_total, lo, hi, reduce, own_dense):
+        """Reduce this rank's edges per destination and split the result by ownership.
+
+        Returns ``(own, ids, rows)``: ``ids`` int64 ascending = the distinct destinations outside [lo, hi) this rank
+        touches, ``rows`` [len(ids), D] their reduced rows. ``own`` is a callable that, when invoked, produces the own
+        part — the dense slab [hi-lo, D] if ``own_dense`` (sum: untouched rows are 0, the neutral element; written into
+        ``out`` when one is passed), else the compact pair (ids_own - lo, rows_own) — so the caller can start the
+        exchange first and overlap the two.
+        """
+        from . import _lib
+        from .ops import REDUCE_CODE, Plan, _dtype_code, _require_gpu, _stream, check
+
+        _require_gpu(src, index)
+        if src.dim() != 2 or index.dim() != 1 or index.numel() != src.size(0):
+            raise ValueError("sharded_scatter: src must be [E, D] with a 1-D index of E destinations")
+        if src.size(0) >= 2 ** 31 or n_total >= 2 ** 31:
+            raise NotImplementedError("sharded_scatter(exchange='sparse'): E and n_total must be < 2^31")
+        src = src.contiguous()
+        E, D = src.shape
+        L = _lib.load()
+        dt = _dtype_code(src, "sharded_scatter")
+        rcode = REDUCE_CODE["sum" if reduce == "add" else reduce]
+        plan = Plan(index, n_total)
+        rowptr, perm = plan.rowptr, plan.perm
+        dev = src.device
+
+        def seg(rp, n_rows, out):
+            # rows of `out` = reduce over perm[rp[i] : rp[i+1]] (absolute positions: any slice of a rowptr works)
+            if n_rows == 0:
+                return
+            with torch.cuda.device(dev):
+                check(L.gnnops_segment_reduce(src.data_ptr(), rp.data_ptr(), perm.data_ptr(), out.data_ptr(), None, 1, E,
+                                              D, n_rows, dt, rcode, 0, _stream()), "segment_reduce")
+
+        touched = rowptr[1:] != rowptr[:-1]
+        own_touched = None if own_dense else touched[lo:hi].nonzero().squeeze(1)
+        touched[lo:hi] = False
+        ids = touched.nonzero().squeeze(1)                       # int64, ascending, remote only
+        n_lo = int(torch.searchsorted(ids, lo).item())           # ids below the own range (owners 0 .. rank-1)
+        n_hi = ids.numel() - n_lo
+        # compact rowptrs: untouched rows are empty, so consecutive touched rows are adjacent in perm
+        crow = torch.cat([rowptr[ids[:n_lo]], rowptr[lo:lo + 1], rowptr[ids[n_lo:]], rowptr[n_total:n_total + 1]])
+        rows = torch.empty((ids.numel(), D), dtype=src.dtype, device=dev)
+        seg(crow[: n_lo + 1], n_lo, rows[:n_lo])
+        seg(crow[n_lo + 1:], n_hi, rows[n_lo:])
+
+        def own(out=None):
+            if own_dense:
+                slab = out if out is not None else torch.empty((hi - lo, D), dtype=src.dtype, device=dev)
+                seg(rowptr[lo:hi + 1], hi - lo, slab)
+                return slab
+            orow = torch.cat([rowptr[lo:hi][own_touched], rowptr[hi:hi + 1]])
+            orows = torch.empty((own_touched.numel(), D), dtype=src.dtype, device=dev)
+            seg(orow, own_touched.numel(), orows)
+            return own_touched, orows
+
+        return own, ids, rows
+
+    def accumulate(self, slab, rows, ids_local, reduce):
+        """slab[ids_local[j]] (+)= rows[j], in place (sum only: the slab's untouched rows hold the neutral 0)."""
+        from .ops import scatter
+
+        if rows.size(0):
+            scatter(rows, ids_local, 0, out=slab, reduce="sum")
+        return slab
+
+    def combine(self, rows, ids_local, n_local, reduce):
+        """Dense slab [n_local, D] from compact contributions; destinations nobody touched read 0 (torch_scatter)."""
+        from .ops import scatter
+
+        res = scatter(rows, ids_local, 0, dim_size=n_local, reduce=reduce)
+        return res[0] if isinstance(res, tuple) else res
+
+
+def _exchange(ids, rows, per, rank, world, group):
+    """All-to-all-v of compact (id, row) lists: ids ascend, so owner o's share is one contiguous slice."""
+    dev = ids.device
+    bounds = torch.searchsorted(ids, torch.arange(world + 1, device=dev, dtype=ids.dtype) * per)
+    send_counts = (bounds[1:] - bounds[:-1]).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    send_splits, recv_splits = send_counts.tolist(), recv_counts.tolist()
+    if send_splits[rank] != 0:
+        raise RuntimeError("sharded_scatter: own destinations must not enter the exchange")
+    n_recv = sum(recv_splits)
+    recv_ids = torch.empty(n_recv, dtype=ids.dtype, device=dev)
+    recv_rows = torch.empty((n_recv,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
+    works = [dist.all_to_all_single(recv_ids, ids, recv_splits, send_splits, group=group, async_op=True),
+             dist.all_to_all_single(recv_rows, rows, recv_splits, send_splits, group=group, async_op=True)]
+    return recv_ids, recv_rows, works
+
+
+def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, local_scatter=None, out_slab=None,
+                    exchange="sparse", local=None):
     """Scatter-reduce this rank's edges into global destinations and return the slab this rank owns.
 
-    sum / min / max use one reduce-scatter; mean = reduce-scatter of sums and of counts, then divide.
+    sum / min / max / mul: one exchange (see the module docstring); mean = sums and counts, then divide.
     (arg_out across ranks needs a (value, index) pair reduction — SURVEY.md §8f — and is not provided.)
+    `local_scatter` given without `local` selects the dense form (it is all that form needs).
     """
-    if local_scatter is None:
-        from .ops import scatter as local_scatter
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = owned_rows(n_total, rank, world)
+    if local is None and local_scatter is not None:
+        exchange = "dense"
+    if exchange not in ("sparse", "dense"):
+        raise ValueError(f"sharded_scatter: unknown exchange {exchange!r}")
     if reduce == "mean":
-        sums = sharded_scatter(src_local, index_local, n_total, "sum", group, local_scatter)
+        kw = dict(group=group, local_scatter=local_scatter, exchange=exchange, local=local)
+        sums = sharded_scatter(src_local, index_local, n_total, "sum", **kw)
         ones = torch.ones((src_local.shape[0], 1), dtype=src_local.dtype, device=src_local.device)
-        cnt = sharded_scatter(ones, index_local, n_total, "sum", group, local_scatter)
-        return sums / cnt.clamp_(min=1)
+        cnt = sharded_scatter(ones, index_local, n_total, "sum", **kw)
+        res = sums / cnt.clamp_(min=1)
+        if out_slab is not None:
+            out_slab.copy_(res)
+            return out_slab
+        return res
+
+    if exchange == "sparse":
+        if reduce not in _SPARSE_REDUCES:
+            raise ValueError(f"sharded_scatter: reduce {reduce!r} is not supported")
+        if local is None:
+            local = HipLocal()
+        own_dense = reduce in ("sum", "add")
+        own, ids, rows = local.split(src_local, index_local, n_total, lo, hi, reduce, own_dense)
+        recv_ids, recv_rows, works = _exchange(ids, rows, hi - lo, rank, world, group)
+        direct = own_dense and out_slab is not None and out_slab.is_contiguous() and out_slab.dtype == src_local.dtype
+        own_part = own(out_slab) if direct else own()          # runs while the all-to-all is in flight
+        for w in works:
+            w.wait()
+        if own_dense:
+            slab = local.accumulate(own_part, recv_rows, recv_ids - lo, reduce)
+        else:
+            own_ids, own_rows = own_part
+            slab = local.combine(torch.cat([own_rows, recv_rows]), torch.cat([own_ids, recv_ids - lo]), hi - lo, reduce)
+        if out_slab is not None and slab is not out_slab:
+            out_slab.copy_(slab)
+            return out_slab
+        return slab
+
+    # ---- dense: partial [n_total, D] + one reduce-scatter
+    if local_scatter is None:
+        from .ops import scatter as local_scatter
     if reduce not in _REDUCE_OP:
-        raise ValueError(f"sharded_scatter: reduce {reduce!r} has no single-collective form")
+        raise ValueError(f"sharded_scatter: reduce {reduce!r} has no single-collective dense form")
     partial = local_scatter(src_local, index_local, 0, None, n_total, reduce)
     if isinstance(partial, tuple):
         partial = partial[0]

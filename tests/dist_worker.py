@@ -23,6 +23,44 @@ def oracle_local_scatter(src, index, dim, out, dim_size, reduce):
     return torch.from_numpy(res)
 
 
+class OracleLocal:
+    """CPU stand-in for gnnops.dist.HipLocal (same contract), on numpy + the oracle: only the exchange logic of
+    sharded_scatter(exchange="sparse") is under test here."""
+
+    def split(self, src, index, n_total, lo, hi, reduce, own_dense):
+        from oracle import oracle
+
+        idx = index.numpy()
+        uniq, inv = np.unique(idx, return_inverse=True)
+        red = oracle.scatter(src.numpy(), inv.astype(np.int64), dim=0, dim_size=len(uniq), reduce=reduce)
+        red = red[0] if isinstance(red, tuple) else red
+        remote = (uniq < lo) | (uniq >= hi)
+        ids = torch.from_numpy(uniq[remote].astype(np.int64))
+        rows = torch.from_numpy(np.ascontiguousarray(red[remote]))
+        own_ids = torch.from_numpy((uniq[~remote] - lo).astype(np.int64))
+        own_rows = torch.from_numpy(np.ascontiguousarray(red[~remote]))
+
+        def own(out=None):
+            if not own_dense:
+                return own_ids, own_rows
+            slab = out if out is not None else torch.empty((hi - lo, src.shape[1]), dtype=src.dtype)
+            slab.zero_()
+            slab[own_ids] = own_rows
+            return slab
+
+        return own, ids, rows
+
+    def accumulate(self, slab, rows, ids_local, reduce):
+        slab.index_add_(0, ids_local, rows)
+        return slab
+
+    def combine(self, rows, ids_local, n_local, reduce):
+        from oracle import oracle
+
+        res = oracle.scatter(rows.numpy(), ids_local.numpy(), dim=0, dim_size=n_local, reduce=reduce)
+        return torch.from_numpy(res[0] if isinstance(res, tuple) else res)
+
+
 def make_inputs(rank, world, n_total, e_local, d):
     g = torch.Generator().manual_seed(100 + rank)
     src = torch.rand(e_local, d, generator=g) * 2 - 1
@@ -40,6 +78,12 @@ def run(rank, world, init_file, n_total, e_local, d, out_dir):
         res = {}
         for r in ("sum", "min", "max", "mean"):
             res[r] = sharded_scatter(src, idx, n_total, r, local_scatter=oracle_local_scatter).numpy()
+        for r in ("sum", "min", "max", "mean", "mul"):
+            res["sparse_" + r] = sharded_scatter(src, idx, n_total, r, local=OracleLocal()).numpy()
+        slab = torch.full((n_total // world, d), 7.0)
+        got = sharded_scatter(src, idx, n_total, "sum", local=OracleLocal(), out_slab=slab)
+        assert got is slab
+        res["sparse_sum_out"] = slab.numpy()
         lo, hi = owned_rows(n_total, rank, world)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi, **res)
     finally:

@@ -1,8 +1,9 @@
 """CPU suite, part 3: the multi-GPU path's host logic (gnnops.dist) on 2 gloo ranks.
 
-The exchange step (one reduce-scatter of the per-rank partial [N, D] buffers) and the row ownership
-are exercised for real; the local reduction is the oracle (the HIP kernels need a GPU). The expected
-result is the oracle on the concatenation of every rank's edges."""
+Both exchange forms — the dense reduce-scatter of per-rank partial [N, D] buffers and the sparse all-to-all-v of
+compact (id, row) lists — and the row ownership are exercised for real; the local reductions are numpy / oracle
+stand-ins (the HIP kernels need a GPU). The expected result is the oracle on the concatenation of every rank's
+edges."""
 import os
 import tempfile
 
@@ -36,6 +37,34 @@ def test_sharded_scatter_two_ranks():
                 else:  # the order ranks are summed in differs from the single sequential pass
                     np.testing.assert_allclose(got[r], exp[lo:hi], rtol=1e-5, atol=1e-5, err_msg=r)
             assert (got["sum"][5 - lo] == 0).all() if lo <= 5 < hi else True
+            for r in ("sum", "min", "max", "mean", "mul"):
+                exp = oracle.scatter(src, idx, dim=0, dim_size=n_total, reduce=r)
+                exp = exp[0] if isinstance(exp, tuple) else exp
+                if r in ("min", "max"):
+                    assert np.array_equal(got["sparse_" + r], exp[lo:hi]), r
+                else:
+                    np.testing.assert_allclose(got["sparse_" + r], exp[lo:hi], rtol=1e-5, atol=1e-5, err_msg=r)
+            np.testing.assert_allclose(got["sparse_sum_out"], got["sparse_sum"], rtol=0, atol=0)
+            assert (got["sparse_sum"][5 - lo] == 0).all() if lo <= 5 < hi else True
+
+
+@pytest.mark.timeout(180)
+def test_sharded_scatter_three_ranks_sparse_only_cut():
+    """Three ranks, more destinations than edges (most rows untouched): owner slices of the compact lists, empty
+    shares and the rank in the middle (ids both below and above its range)."""
+    world, n_total, e_local, d = 3, 300, 40, 4
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "init")
+        mp.spawn(dist_worker.run, args=(world, init_file, n_total, e_local, d, tmp), nprocs=world, join=True)
+        srcs, idxs = zip(*(dist_worker.make_inputs(r, world, n_total, e_local, d) for r in range(world)))
+        src, idx = torch.cat(srcs).numpy(), torch.cat(idxs).numpy()
+        for rank in range(world):
+            got = np.load(os.path.join(tmp, f"rank{rank}.npz"))
+            lo, hi = int(got["lo"]), int(got["hi"])
+            for r in ("sum", "min", "max", "mean", "mul"):
+                exp = oracle.scatter(src, idx, dim=0, dim_size=n_total, reduce=r)
+                exp = exp[0] if isinstance(exp, tuple) else exp
+                np.testing.assert_allclose(got["sparse_" + r], exp[lo:hi], rtol=1e-5, atol=1e-5, err_msg=r)
 
 
 def test_owned_rows_requires_divisibility():

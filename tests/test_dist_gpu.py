@@ -1,0 +1,103 @@
+"""GPU parity of the per-rank pieces of gnnops.dist (HipLocal) — the split of one rank's edges into the own slab and the
+compact remote (id, row) lists, and the two ways the received lists are folded in — against the oracle, as if this GPU
+were rank 1 of 3 (destinations both below and above its range). The exchange itself is covered on CPU (test_dist_cpu.py,
+gloo) and by bench.py's one-rank RCCL rehearsal; this box has one GPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def local():
+    import gnnops
+    from gnnops.dist import HipLocal
+
+    gnnops.load_library()
+    return HipLocal()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+def _inputs(E, n_total, D, seed, holes=True):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.rand(E, D, generator=g) * 2 - 1
+    idx = torch.randint(0, n_total, (E,), generator=g)
+    if holes:
+        idx[idx % 7 == 3] = 0  # many untouched destinations, one heavy one
+    return src, idx
+
+
+@pytest.mark.parametrize("reduce", ["sum", "min", "max", "mul"])
+@pytest.mark.parametrize("E,n_total,D", [(5000, 900, 16), (300, 3000, 5), (0, 30, 4), (40000, 300, 128)])
+def test_split_matches_oracle(local, oracle, reduce, E, n_total, D):
+    src, idx = _inputs(E, n_total, D, 11)
+    lo, hi = n_total // 3, 2 * n_total // 3
+    own_dense = reduce == "sum"
+    own, ids, rows = local.split(src.cuda(), idx.cuda(), n_total, lo, hi, reduce, own_dense)
+    exp = oracle.scatter(src.numpy(), idx.numpy(), dim=0, dim_size=n_total, reduce=reduce)
+    exp = exp[0] if isinstance(exp, tuple) else exp
+    touched = np.bincount(idx.numpy(), minlength=n_total) > 0
+    remote = touched.copy()
+    remote[lo:hi] = False
+    assert np.array_equal(ids.cpu().numpy(), np.nonzero(remote)[0])
+    assert np.array_equal(rows.cpu().numpy(), exp[remote])  # sequential order inside a destination: bit-exact
+    part = own()
+    if own_dense:
+        assert np.array_equal(part.cpu().numpy(), exp[lo:hi])
+        buf = torch.full((hi - lo, D), 3.0, device="cuda")
+        assert own(buf) is buf and np.array_equal(buf.cpu().numpy(), exp[lo:hi])
+    else:
+        own_ids, own_rows = part
+        assert np.array_equal(own_ids.cpu().numpy(), np.nonzero(touched[lo:hi])[0])
+        assert np.array_equal(own_rows.cpu().numpy(), exp[lo:hi][touched[lo:hi]])
+
+
+def test_accumulate_and_combine(local, oracle):
+    n_local, D = 500, 12
+    g = torch.Generator().manual_seed(5)
+    slab = torch.rand(n_local, D, generator=g)
+    rows = torch.rand(800, D, generator=g)
+    ids = torch.randint(0, n_local, (800,), generator=g)
+    exp = slab.numpy().copy()
+    np.add.at(exp, ids.numpy(), rows.numpy())
+    got = local.accumulate(slab.cuda(), rows.cuda(), ids.cuda(), "sum").cpu().numpy()
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6)
+    empty = local.accumulate(slab.cuda(), rows[:0].cuda(), ids[:0].cuda(), "sum")
+    assert torch.equal(empty.cpu(), slab)
+    for r in ("min", "max", "mul", "sum"):
+        e = oracle.scatter(rows.numpy(), ids.numpy(), dim=0, dim_size=n_local, reduce=r)
+        e = e[0] if isinstance(e, tuple) else e
+        assert np.array_equal(local.combine(rows.cuda(), ids.cuda(), n_local, r).cpu().numpy(), e), r
+
+
+def test_sharded_scatter_single_rank_rccl(oracle):
+    """World size 1 over RCCL: no remote destinations, empty all-to-all — the whole call path on the device."""
+    import os
+    import tempfile
+
+    import torch.distributed as dist
+
+    from gnnops.dist import sharded_scatter
+
+    src, idx = _inputs(3000, 400, 8, 3)
+    with tempfile.TemporaryDirectory() as tmp:
+        dist.init_process_group("nccl", init_method=f"file://{os.path.join(tmp, 'init')}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        try:
+            for r in ("sum", "min", "mean"):
+                got = sharded_scatter(src.cuda(), idx.cuda(), 400, r).cpu().numpy()
+                exp = oracle.scatter(src.numpy(), idx.numpy(), dim=0, dim_size=400, reduce=r)
+                exp = exp[0] if isinstance(exp, tuple) else exp
+                np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6, err_msg=r)
+            dense = sharded_scatter(src.cuda(), idx.cuda(), 400, "sum", exchange="dense").cpu().numpy()
+            np.testing.assert_allclose(dense, oracle.scatter(src.numpy(), idx.numpy(), dim=0, dim_size=400, reduce="sum"),
+                                       rtol=1e-6, atol=1e-6)
+        finally:
+            dist.destroy_process_group()
