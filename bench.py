@@ -135,7 +135,7 @@ def main():
     value = job_bytes / (elapsed / args.steps) / 1e9
 
     result = {
-        "metric": "scatter_add effective HBM GB/s (algorithmic bytes / wall time, cold: plan build + segment reduce per call)",
+        "metric": "scatter_add effective HBM GB/s (algorithmic bytes / wall time, cold: index partition + bucketed segment reduce per call)",
         "value": round(value, 1),
         "unit": "GB/s",
         "n_gpus": world,
@@ -233,19 +233,35 @@ def _event_ms(torch, fn, iters):
 
 
 def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters, pmc_applies):
-    """Dominant kernel: seg_rows_kernel<float, SUM> (one launch of gnnops_segment_reduce over a prebuilt plan)."""
+    """Dominant kernel of the timed step: bucket_reduce_kernel<float, SUM> — one launch of gnnops_bucket_reduce over a
+    workspace gnnops_bucket_partition filled (the two stages of the one-shot scatter the step runs). Beside it, the
+    plan-path kernel seg_rows_kernel<float, SUM> (what a call that reuses a plan runs)."""
     from gnnops import _lib
     from gnnops.ops import _stream
 
-    plan = gnnops.Plan(index, N)
     out = torch.empty(N, D, device=src.device, dtype=torch.float32)
+    ws_bytes = lib.gnnops_bucket_workspace_bytes(E, N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
+
+    def partition():
+        _lib.check(lib.gnnops_bucket_partition(index.data_ptr(), E, N, ws.data_ptr(), ws_bytes, _stream()), "bucket_partition")
 
     def launch():
+        _lib.check(lib.gnnops_bucket_reduce(src.data_ptr(), ws.data_ptr(), out.data_ptr(), None, E, D, N, _lib.F32, _lib.SUM,
+                                            0, _stream()), "bucket_reduce")
+
+    partition_ms = _event_ms(torch, partition, 3)
+    ms = _event_ms(torch, launch, max(iters, 5))
+    del ws
+
+    plan = gnnops.Plan(index, N)
+
+    def launch_seg():
         rc = lib.gnnops_segment_reduce(src.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(), out.data_ptr(), None,
                                        1, E, D, N, _lib.F32, _lib.SUM, 0, _stream())
         _lib.check(rc, "segment_reduce")
 
-    ms = _event_ms(torch, launch, max(iters, 5))
+    seg_ms = _event_ms(torch, launch_seg, max(iters, 5))
     plan_ms = _event_ms(torch, lambda: gnnops.Plan(index, N), 3)
     alg = algorithmic_bytes("scatter_add", N, E, D)
     achieved = alg / (ms * 1e-3) / 1e9
@@ -253,11 +269,11 @@ def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters, pmc_applies):
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if pmc_applies and os.path.exists(tpath):  # the committed PMC passes were taken at config 2
         try:
-            traffic = json.load(open(tpath)).get("seg_rows_kernel_f32_sum", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("bucket_reduce_kernel_f32_sum", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     return {
-        "kernel": "seg_rows_kernel<float,SUM> (gnnops_segment_reduce)",
+        "kernel": "bucket_reduce_kernel<float,SUM> (gnnops_bucket_reduce)",
         "bound": "hbm",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
@@ -266,7 +282,9 @@ def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters, pmc_applies):
         "traffic": traffic,
         "kernel_ms": round(ms, 4),
         "algorithmic_bytes_per_launch": alg,
-        "plan_build_ms": round(plan_ms, 4),
+        "partition_ms": round(partition_ms, 4),
+        "plan_path": {"kernel": "seg_rows_kernel<float,SUM> (gnnops_segment_reduce)", "kernel_ms": round(seg_ms, 4),
+                      "frac": round(alg / (seg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "plan_build_ms": round(plan_ms, 4)},
     }
 
 

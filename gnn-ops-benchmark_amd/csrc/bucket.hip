@@ -1,0 +1,388 @@
+// bucket.hip — one-shot row scatter (torch_scatter.scatter_{add,mean,min,max,mul} with a row index, Tensor.index_add_;
+// reference call sites as in segment.hip) when there is no plan to reuse: the LAST radix pass of the plan build, the
+// row-pointer kernel and the perm / rowptr round trip through HBM are folded into the reduction.
+//
+//   1. global stable LSD passes over the destination bits ABOVE the low 8 (sort_engine): edges end up grouped by
+//      bucket = destination >> 8 (256 consecutive output rows), in source order inside a bucket;
+//   2. bucket_bounds_kernel: one binary search per bucket boundary (no pass over the keys);
+//   3. bucket_reduce_kernel: a workgroup takes a bucket, finishes the sort ON CHIP — a stable counting sort of its
+//      (destination & 255, source position) pairs in LDS, ballot ranking as in sort_engine_impl.h — and then runs the
+//      segment reduction of segment.hip with the permutation and row pointers read from LDS instead of HBM.
+//
+// Same arithmetic and order as seg_rows_kernel (contributions of a destination in ascending source position), so the
+// result is bit-identical to the plan path and to the sequential oracle. Against plan build + segment reduce at config 2
+// this drops one scatter pass, its histogram/scan, the rowptr kernel and ~0.25 GB of perm/rowptr reads.
+//
+// A bucket larger than CAP entries (skewed destinations) is processed in chunks of CAP in source order: chunk c > 0
+// starts from the output rows (and arg rows) chunk c-1 stored — the same sequence of operations when the output type
+// holds the running value exactly, i.e. fp32 for every reduce and any type for min / max; the host side (ops.py) keeps
+// 16-bit sums / means / products on the plan path, where the fp32 accumulator is rounded once.
+#include "common.h"
+#include "sort_engine.h"
+
+namespace {
+
+constexpr int BSHIFT = 8, BROWS = 1 << BSHIFT;  // destinations per bucket
+constexpr int THREADS = 256, WAVES = THREADS / 64;
+constexpr int ROUNDS = 16, CAP = THREADS * ROUNDS;  // entries sorted on chip at a time
+constexpr int U = 8;                                // contribution rows in flight per lane group
+constexpr bool NT = true;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int key_bits(int64_t N) {
+    int bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < N) ++bits;
+    return bits;
+}
+
+// bptr[b] = first position whose key >> BSHIFT >= b (keys are sorted by that quantity); bptr[NB] = E.
+__global__ void bucket_bounds_kernel(const uint32_t* __restrict__ keys, int64_t E, int64_t NB, int32_t* __restrict__ bptr) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > NB) return;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(keys[mid] >> BSHIFT) < b) lo = mid + 1; else hi = mid;
+    }
+    bptr[b] = (int32_t)lo;
+}
+
+// 16-B load that does not trust this CU's L1 (rows a previous chunk of the same workgroup stored).
+template <typename T>
+__device__ inline u32x4 load16_coherent(const T* p) {
+    const volatile uint32_t* q = reinterpret_cast<const volatile uint32_t*>(p);
+    return u32x4{q[0], q[1], q[2], q[3]};
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restrict__ src, const uint32_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ vals,
+                                                                const int32_t* __restrict__ bptr, T* __restrict__ out,
+                                                                int64_t* __restrict__ arg_out, int64_t E, int64_t K,
+                                                                int64_t N, int64_t NB, int gshift, int kchunks,
+                                                                int init_from_out, int is_mean) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
+    __shared__ int32_t s_perm[CAP];
+    __shared__ uint32_t s_whist[WAVES * 256];
+    __shared__ int32_t s_rowptr[BROWS + 1];
+    __shared__ uint32_t s_cnt[BROWS];  // contributions per destination over all chunks of the bucket
+    __shared__ uint32_t s_tmp[WAVES];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t* whist = s_whist + wave * 256;
+    const int G = 1 << gshift;
+    const int gl = tid & (G - 1);
+    const int gi = tid >> gshift, groups = THREADS >> gshift;
+
+    for (int64_t bucket = blockIdx.x; bucket < NB; bucket += gridDim.x) {
+        const int32_t bbeg = bptr[bucket], bend = bptr[bucket + 1];
+        for (int32_t cbeg = bbeg;; cbeg += CAP) {
+            const bool first = cbeg == bbeg;
+            const bool last = cbeg + CAP >= bend;
+            const int n = (bend - cbeg < CAP) ? (bend - cbeg) : CAP;
+            __syncthreads();  // previous chunk's / bucket's readers are done with s_perm, s_rowptr, s_cnt, s_whist
+            if (first) s_cnt[tid] = 0;
+            for (int i = tid; i < WAVES * 256; i += THREADS) s_whist[i] = 0;
+            __syncthreads();
+
+            // ---- stable counting sort of (destination & 255, source position) by the 8-bit key
+            const int rounds_n = (n + THREADS - 1) / THREADS;   // rows of 64 per wave; a wave owns consecutive rows
+            const int wave_base = wave * rounds_n * 64;
+            uint32_t dg[ROUNDS], vv[ROUNDS], rk[ROUNDS];
+            uint32_t is_leader = 0;
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                dg[r] = 0; vv[r] = 0; rk[r] = 0;
+                if (r < rounds_n) {
+                    const int i = wave_base + r * 64 + lane;
+                    const bool valid = i < n;
+                    if (valid) {
+                        dg[r] = keys[cbeg + i] & (BROWS - 1);
+                        vv[r] = vals[cbeg + i];
+                    }
+                    const uint32_t d = dg[r];
+                    const uint64_t vb = __ballot(valid);
+                    uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+                        const uint64_t bal = __ballot(xb != 0u);
+                        m_lo &= ~((uint32_t)bal ^ xb);
+                        m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
+                    }
+                    const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;   // valid lanes with my digit
+                    const uint32_t below = __popcll(m & lanes_below);
+                    if (valid && below == 0) {
+                        rk[r] = atomicAdd(&whist[d], (uint32_t)__popcll(m));  // rank of the group inside this wave
+                        is_leader |= 1u << r;
+                    } else {
+                        rk[r] = below | ((uint32_t)(__ffsll((unsigned long long)m) - 1) << 16);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                if (r < rounds_n) {
+                    const bool lead = (is_leader >> r) & 1u;
+                    const int from = lead ? lane : (int)((rk[r] >> 16) & 63u);
+                    const uint32_t p = __shfl(rk[r], from);
+                    rk[r] = lead ? p : p + (rk[r] & 0xffffu);
+                }
+            }
+            __syncthreads();
+            {   // digit offsets: exclusive over waves, then over digits (thread d owns digit d)
+                uint32_t tot = 0;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) {
+                    const uint32_t c = s_whist[w * 256 + tid];
+                    s_whist[w * 256 + tid] = tot;
+                    tot += c;
+                }
+                const uint32_t start = block_excl_scan_u32<WAVES>(tot, s_tmp, nullptr);
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) s_whist[w * 256 + tid] += start;
+                s_rowptr[tid] = (int32_t)start;
+                if (tid == BROWS - 1) s_rowptr[BROWS] = (int32_t)(start + tot);
+                s_cnt[tid] += tot;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                if (r < rounds_n) {
+                    const int i = wave_base + r * 64 + lane;
+                    if (i < n) s_perm[whist[dg[r]] + rk[r]] = (int32_t)vv[r];
+                }
+            }
+            __syncthreads();
+
+            // ---- segment reduction of the bucket's rows (segment.hip's loop, indices from LDS)
+            const bool from_out = first ? (init_from_out != 0) : true;
+            for (int item = gi; item < BROWS * kchunks; item += groups) {
+                const int dloc = item & (BROWS - 1);
+                const int chunk = item >> BSHIFT;
+                const int64_t nrow = bucket * BROWS + dloc;
+                const int64_t col = ((int64_t)chunk * G + gl) * VEC;
+                if (nrow >= N || col >= K) continue;
+                const int32_t beg = s_rowptr[dloc], end = s_rowptr[dloc + 1];
+                const T* srcb = src + col;
+                const int64_t oidx = nrow * K + col;
+
+                float acc[VEC];
+                int32_t arg[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) arg[v] = (int32_t)E;
+                if (from_out) {
+                    u32x4 r = first ? *reinterpret_cast<const u32x4*>(out + oidx) : load16_coherent(out + oidx);
+                    Elem<T>::unpack(r, acc);
+                    if constexpr (IS_ARG) {
+                        if (!first && arg_out) {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                arg[v] = (int32_t)reinterpret_cast<const volatile int64_t*>(arg_out + oidx)[v];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = Red<R>::identity();
+                }
+
+                for (int32_t j = beg; j < end; j += U) {
+                    int32_t e[U];
+                    u32x4 rows[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) e[u] = (j + u < end) ? s_perm[j + u] : -1;
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (e[u] >= 0) rows[u] = load16<NT>(srcb + (int64_t)e[u] * K);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (e[u] >= 0) {
+                            float f[VEC];
+                            Elem<T>::unpack(rows[u], f);
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) {
+                                if constexpr (IS_ARG) {
+                                    if (Red<R>::better(f[v], acc[v])) { acc[v] = f[v]; arg[v] = e[u]; }
+                                } else {
+                                    acc[v] = Red<R>::apply(acc[v], f[v]);
+                                }
+                            }
+                        }
+                    }
+                }
+
+                if constexpr (IS_ARG) {
+                    // torch_scatter: groups nothing reached become 0 (decided once the whole bucket has been seen)
+                    if (last && !init_from_out && s_cnt[dloc] == 0) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+                    }
+                    if (arg_out) {
+                        int64_t a[VEC];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) a[v] = arg[v];
+                        u32x4* ap = reinterpret_cast<u32x4*>(arg_out + oidx);
+                        const u32x4* as = reinterpret_cast<const u32x4*>(a);
+#pragma unroll
+                        for (int q = 0; q < VEC / 2; ++q) ap[q] = as[q];
+                    }
+                } else if (R == GNNOPS_SUM) {
+                    if (is_mean && last) {
+                        const uint32_t cnt = s_cnt[dloc];
+                        const float c = (float)(cnt < 1 ? 1 : cnt);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[v] = acc[v] / c;
+                    }
+                }
+                store16<NT>(out + oidx, Elem<T>::pack(acc));
+            }
+            if (last) break;
+            __threadfence();  // the next chunk re-reads the rows just stored
+        }
+    }
+}
+
+template <typename T, int R>
+int launch_bucket(const void* src, const uint32_t* keys, const uint32_t* vals, const int32_t* bptr, void* out,
+                  int64_t* arg_out, int64_t E, int64_t K, int64_t N, int64_t NB, int init_from_out, int is_mean,
+                  hipStream_t stream) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int64_t vecs = K / VEC;
+    int gshift = 0;
+    while ((1 << gshift) < vecs && gshift < 6) ++gshift;
+    const int kchunks = (int)gnnops_cdiv(vecs, (int64_t)1 << gshift);
+    const int grid = gnnops_grid_cap(NB, 256 * 16);
+    hipLaunchKernelGGL((bucket_reduce_kernel<T, R>), dim3(grid), dim3(THREADS), 0, stream, (const T*)src, keys, vals, bptr,
+                       (T*)out, arg_out, E, K, N, NB, gshift, kchunks, init_from_out, is_mean);
+    return gnnops_check_launch("scatter_rows_oneshot");
+}
+
+template <typename T>
+int dispatch_bucket(int reduce, const void* src, const uint32_t* keys, const uint32_t* vals, const int32_t* bptr, void* out,
+                    int64_t* arg_out, int64_t E, int64_t K, int64_t N, int64_t NB, int init_from_out, hipStream_t stream) {
+    switch (reduce) {
+        case GNNOPS_SUM: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream);
+        case GNNOPS_MEAN: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 1, stream);
+        case GNNOPS_MUL: return launch_bucket<T, GNNOPS_MUL>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream);
+        case GNNOPS_MIN: return launch_bucket<T, GNNOPS_MIN>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream);
+        case GNNOPS_MAX: return launch_bucket<T, GNNOPS_MAX>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream);
+    }
+    gnnops_set_error("scatter_rows_oneshot: unknown reduce %d", reduce);
+    return GNNOPS_EINVAL;
+}
+
+struct Layout {
+    size_t keys_a, keys_b, vals_a, vals_b, tile_hist, digit_total, bptr, total;
+};
+inline Layout layout(int64_t E, int64_t N) {
+    Layout l{};
+    const size_t tiles = (size_t)gnnops_cdiv(E > 0 ? E : 1, sortengine::TILE);
+    size_t o = 0;
+    l.keys_a = o; o += align_up((size_t)E * 4, 256);
+    l.keys_b = o; o += align_up((size_t)E * 4, 256);
+    l.vals_a = o; o += align_up((size_t)E * 4, 256);
+    l.vals_b = o; o += align_up((size_t)E * 4, 256);
+    l.tile_hist = o; o += align_up(256 * tiles * 4, 256);
+    l.digit_total = o; o += 256 * 4;
+    l.bptr = o; o += align_up(((size_t)gnnops_cdiv(N, BROWS) + 1) * 4, 256);
+    l.total = o;
+    return l;
+}
+
+// Which ping-pong buffer holds the partitioned (key, position) pairs: fixed by N.
+inline int partition_passes(int64_t N) { return (key_bits(N) - BSHIFT + 7) / 8; }  // LSD passes over bits [BSHIFT, bits)
+
+inline bool oneshot_shape_ok(int64_t E, int64_t N) {
+    return N > BROWS && E > 0 && E < ((int64_t)1 << 31) && N < ((int64_t)1 << 31);
+}
+
+}  // namespace
+
+extern "C" size_t gnnops_bucket_workspace_bytes(int64_t E, int64_t N) {
+    if (E < 0 || N < 0) return 0;
+    return layout(E, N).total;
+}
+
+// Stage 1: group the E positions by bucket = index >> 8, in position order inside a bucket, and find the bucket
+// boundaries. The workspace then IS the partition: gnnops_bucket_reduce may be called on it any number of times.
+extern "C" int gnnops_bucket_partition(const int64_t* index, int64_t E, int64_t N, void* workspace, size_t workspace_bytes,
+                                       gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(E >= 0 && N >= 0, GNNOPS_EINVAL, "bucket_partition: negative size");
+    GNNOPS_REQUIRE(oneshot_shape_ok(E, N), GNNOPS_EUNSUPPORTED,
+                   "bucket_partition: shape outside the bucketed form (E=%lld N=%lld)", (long long)E, (long long)N);
+    GNNOPS_REQUIRE(index, GNNOPS_EINVAL, "bucket_partition: null pointer");
+    const Layout l = layout(E, N);
+    GNNOPS_REQUIRE(workspace && workspace_bytes >= l.total, GNNOPS_EWORKSPACE, "bucket_partition: workspace %zu < %zu",
+                   workspace_bytes, l.total);
+    char* w = (char*)workspace;
+    uint32_t* kbuf[2] = {(uint32_t*)(w + l.keys_a), (uint32_t*)(w + l.keys_b)};
+    uint32_t* vbuf[2] = {(uint32_t*)(w + l.vals_a), (uint32_t*)(w + l.vals_b)};
+    uint32_t* tile_hist = (uint32_t*)(w + l.tile_hist);
+    uint32_t* digit_total = (uint32_t*)(w + l.digit_total);
+    int32_t* bptr = (int32_t*)(w + l.bptr);
+    const int tiles = (int)gnnops_cdiv(E, sortengine::TILE);
+    const int passes = partition_passes(N);  // >= 1 because N > 256
+    const uint32_t* kin = nullptr;
+    const uint32_t* vin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        uint32_t* kout = kbuf[p & 1];
+        uint32_t* vout = vbuf[p & 1];
+        const int rc = (p == 0) ? sortengine::pass_first_i64(index, kout, vout, E, BSHIFT, tile_hist, digit_total, tiles, stream)
+                                : sortengine::pass_u32(kin, vin, kout, vout, E, BSHIFT + 8 * p, tile_hist, digit_total, tiles, stream);
+        if (rc != GNNOPS_OK) return rc;
+        kin = kout; vin = vout;
+    }
+    const int64_t NB = gnnops_cdiv(N, BROWS);
+    hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)gnnops_cdiv(NB + 1, 256)), dim3(256), 0, stream, kin, E, NB, bptr);
+    return gnnops_check_launch("bucket_partition");
+}
+
+// Stage 2: out[n, :] = reduce over { src[e, :] : index[e] == n } in ascending e, from a workspace gnnops_bucket_partition
+// filled for the same (E, N). src [E, K], out [N, K]; arg_out [N, K] int64 or NULL (min / max only).
+extern "C" int gnnops_bucket_reduce(const void* src, const void* workspace, void* out, int64_t* arg_out, int64_t E, int64_t K,
+                                    int64_t N, int dtype, int reduce, int init_from_out, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(E >= 0 && K >= 0 && N >= 0, GNNOPS_EINVAL, "bucket_reduce: negative size");
+    GNNOPS_REQUIRE(!(reduce == GNNOPS_MEAN && init_from_out), GNNOPS_EINVAL, "bucket_reduce: mean cannot start from out");
+    GNNOPS_REQUIRE(dtype == GNNOPS_F32 || dtype == GNNOPS_F16 || dtype == GNNOPS_BF16, GNNOPS_EINVAL,
+                   "bucket_reduce: unknown dtype %d", dtype);
+    const int vec = dtype == GNNOPS_F32 ? 4 : 8;
+    const bool rows_ok = K > 0 && K % vec == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+                         (arg_out == nullptr || (uintptr_t)arg_out % 16 == 0);
+    GNNOPS_REQUIRE(rows_ok && oneshot_shape_ok(E, N), GNNOPS_EUNSUPPORTED,
+                   "bucket_reduce: shape outside the bucketed form (E=%lld K=%lld N=%lld)", (long long)E, (long long)K,
+                   (long long)N);
+    GNNOPS_REQUIRE(src && workspace && out, GNNOPS_EINVAL, "bucket_reduce: null pointer");
+    const Layout l = layout(E, N);
+    const char* w = (const char*)workspace;
+    const int last = (partition_passes(N) - 1) & 1;
+    const uint32_t* keys = (const uint32_t*)(w + (last ? l.keys_b : l.keys_a));
+    const uint32_t* vals = (const uint32_t*)(w + (last ? l.vals_b : l.vals_a));
+    const int32_t* bptr = (const int32_t*)(w + l.bptr);
+    const int64_t NB = gnnops_cdiv(N, BROWS);
+    switch (dtype) {
+        case GNNOPS_F32: return dispatch_bucket<float>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream);
+        case GNNOPS_F16: return dispatch_bucket<__half>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream);
+        default: return dispatch_bucket<__hip_bfloat16>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream);
+    }
+}
+
+// Both stages in one call — what a scatter with no plan to reuse runs. GNNOPS_EUNSUPPORTED (take the plan path instead)
+// when the rows are not 16-B lane rows (K % (16 / elem) != 0 or unaligned pointers), N <= 256, E == 0 or E / N >= 2^31.
+extern "C" int gnnops_scatter_rows_oneshot(const void* src, const int64_t* index, void* out, int64_t* arg_out, int64_t E,
+                                           int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
+                                           void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(E >= 0 && K >= 0 && N >= 0, GNNOPS_EINVAL, "scatter_rows_oneshot: negative size");
+    const int vec = dtype == GNNOPS_F32 ? 4 : 8;
+    const bool rows_ok = K > 0 && K % vec == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+                         (arg_out == nullptr || (uintptr_t)arg_out % 16 == 0);
+    GNNOPS_REQUIRE(rows_ok && oneshot_shape_ok(E, N), GNNOPS_EUNSUPPORTED,
+                   "scatter_rows_oneshot: shape outside the one-shot form (E=%lld K=%lld N=%lld)", (long long)E,
+                   (long long)K, (long long)N);
+    const int rc = gnnops_bucket_partition(index, E, N, workspace, workspace_bytes, s);
+    if (rc != GNNOPS_OK) return rc;
+    return gnnops_bucket_reduce(src, workspace, out, arg_out, E, K, N, dtype, reduce, init_from_out, s);
+}

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgnnops.so")
 
 F32, F16, BF16 = 0, 1, 2
 SUM, MEAN, MIN, MAX, MUL = 0, 1, 2, 3, 4
+OK, EINVAL, EWORKSPACE, ELAUNCH, EUNSUPPORTED = 0, 1, 2, 3, 4  # status codes of include/gnnops.h
 REDUCE_CODE = {"sum": SUM, "add": SUM, "mean": MEAN, "min": MIN, "max": MAX, "mul": MUL}
 
 # name -> (restype, argtypes); must list every symbol include/gnnops.h declares (tests check this).
@@ -22,6 +23,10 @@ SIGNATURES = {
     "gnnops_plan_workspace_bytes": (_sz, [_i64, _i64]),
     "gnnops_plan_build": (_ci, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "gnnops_segment_reduce": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp]),
+    "gnnops_bucket_workspace_bytes": (_sz, [_i64, _i64]),
+    "gnnops_bucket_partition": (_ci, [_vp, _i64, _i64, _vp, _sz, _vp]),
+    "gnnops_bucket_reduce": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _ci, _ci, _vp]),
+    "gnnops_scatter_rows_oneshot": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
     "gnnops_scatter_elementwise_workspace_bytes": (_sz, [_i64, _i64, _i64, _ci, _ci]),
     "gnnops_scatter_elementwise": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
     "gnnops_index_select": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
@@ -80,6 +85,6 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().gnnops_last_error().decode("utf-8", "replace")
-        if rc == 4:
+        if rc == EUNSUPPORTED:
             raise NotImplementedError(f"gnnops.{what}: {msg}")
         raise GnnopsError(f"gnnops.{what} failed (code {rc}): {msg}")

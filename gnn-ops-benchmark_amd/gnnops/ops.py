@@ -258,6 +258,18 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
     if row_index is not None and not is_plan and (E >= 2 ** 31 or N >= 2 ** 31):
         row_index = None  # beyond the plan's int32 range: the element-wise kernel takes int64 sizes
     with torch.cuda.device(src.device):
+        if row_index is not None and not is_plan and B == 1 and not _plan_cache_enabled and E > 0 and (
+                src.dtype == torch.float32 or want_arg):
+            # nothing will reuse a plan: fold the end of its construction into the reduction (bucket.hip). 16-bit
+            # sums / means / products stay on the plan path (one rounding of the fp32 accumulator, whatever the skew).
+            ws_bytes = L.gnnops_bucket_workspace_bytes(E, N)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=src.device)
+            rc = L.gnnops_scatter_rows_oneshot(src.data_ptr(), row_index.data_ptr(), out.data_ptr(),
+                                               arg.data_ptr() if want_arg else None, E, K, N, dt, rcode, init,
+                                               ws.data_ptr(), ws_bytes, _stream())
+            if rc != _lib.EUNSUPPORTED:
+                check(rc, "scatter_rows_oneshot")
+                return (out, arg) if want_arg else out
         if row_index is not None:
             plan = get_plan(row_index, N)
             rc = L.gnnops_segment_reduce(src.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(), out.data_ptr(),

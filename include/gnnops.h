@@ -90,6 +90,28 @@ int gnnops_segment_reduce(const void* src, const int32_t* rowptr, const int32_t*
                           int dtype, int reduce, int init_from_out, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * One-shot row scatter — the same reference call sites as gnnops_segment_reduce (layout R, B == 1), for
+ * a call that has no plan to reuse: src [E,K], index [E] int64 in [0,N), out [N,K] (arg_out as above).
+ * Equivalent to gnnops_plan_build + gnnops_segment_reduce (same order of operations, bit-identical
+ * results) but the last radix pass, the row-pointer kernel and the perm/rowptr round trip through HBM
+ * are folded into the reduction (bucket.hip). Returns GNNOPS_EUNSUPPORTED — take the plan path — when
+ * K * elem is not a whole number of 16-B lanes, pointers are not 16-B aligned, N <= 256, E == 0, or
+ * E / N >= 2^31.
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_scatter_rows_oneshot(const void* src, const int64_t* index, void* out, int64_t* arg_out,
+                                int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
+                                void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+/* The two stages separately: gnnops_bucket_partition groups the E positions by bucket = index >> 8 (stable) into the
+ * workspace — which then is a reusable, coarser plan — and gnnops_bucket_reduce runs the reduction from it (the on-chip
+ * finish of the sort is repeated per call; the indices never travel through HBM as rowptr / perm). */
+size_t gnnops_bucket_workspace_bytes(int64_t E, int64_t N);
+int gnnops_bucket_partition(const int64_t* index, int64_t E, int64_t N, void* workspace, size_t workspace_bytes,
+                            gnnops_stream_t stream);
+int gnnops_bucket_reduce(const void* src, const void* workspace, void* out, int64_t* arg_out,
+                         int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
+                         gnnops_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Element-wise scatter, layout F (index has the shape of src) — what the reference scripts build
  * (benchmark_scatter_add.py:67,78-84; native form `zeros_like(src).scatter_add_(dim, idx, src)`
  * benchmark_scatter_add.py:22-25; `scatter_(-1, idx, src, reduce="multiply")`

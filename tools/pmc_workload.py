@@ -16,6 +16,9 @@ for _ in range(3):
     out = gnnops.scatter_add(src, plan, 0)
     mn = gnnops.scatter_min(src, plan, 0)
     del out, mn
+    out = gnnops.scatter_add(src, idx, 0, dim_size=N)   # plan cache off: the one-shot form (bucket_reduce_kernel)
+    mn = gnnops.scatter_min(src, idx, 0, dim_size=N)
+    del out, mn
 del src
 table = torch.rand(N, D, generator=g, device=dev)
 for _ in range(3):
