@@ -54,6 +54,86 @@ __device__ inline u32x4 load16_coherent(const T* p) {
     return u32x4{q[0], q[1], q[2], q[3]};
 }
 
+// Stable counting sort, in LDS, of the n <= CAP (key & 255, position) pairs at [cbeg, cbeg + n): s_perm gets the positions
+// grouped by key in their original order, s_rowptr[0..256] the group boundaries. Returns the size of group `threadIdx.x`.
+// Ranking as in sort_engine_impl.h: a wave owns consecutive rows of 64 pairs; eight ballots give every lane the mask of
+// its equal-key lanes; the lowest of them does ONE returning LDS add for the group. The caller must have passed a
+// barrier since the last readers of the LDS arrays; s_perm / s_rowptr are valid after the caller's next barrier.
+__device__ inline uint32_t sort_chunk(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int32_t cbeg, int n,
+                                      int32_t* s_perm, uint32_t* s_whist, int32_t* s_rowptr, uint32_t* s_tmp) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t* whist = s_whist + wave * 256;
+    for (int i = tid; i < WAVES * 256; i += THREADS) s_whist[i] = 0;
+    __syncthreads();
+    const int rounds_n = (n + THREADS - 1) / THREADS;   // rows of 64 per wave
+    const int wave_base = wave * rounds_n * 64;
+    uint32_t dg[ROUNDS], vv[ROUNDS], rk[ROUNDS];
+    uint32_t is_leader = 0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        dg[r] = 0; vv[r] = 0; rk[r] = 0;
+        if (r < rounds_n) {
+            const int i = wave_base + r * 64 + lane;
+            const bool valid = i < n;
+            if (valid) {
+                dg[r] = keys[cbeg + i] & (BROWS - 1);
+                vv[r] = vals[cbeg + i];
+            }
+            const uint32_t d = dg[r];
+            const uint64_t vb = __ballot(valid);
+            uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+                const uint64_t bal = __ballot(xb != 0u);
+                m_lo &= ~((uint32_t)bal ^ xb);
+                m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
+            }
+            const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;   // valid lanes with my key
+            const uint32_t below = __popcll(m & lanes_below);
+            if (valid && below == 0) {
+                rk[r] = atomicAdd(&whist[d], (uint32_t)__popcll(m));  // rank of the group inside this wave
+                is_leader |= 1u << r;
+            } else {
+                rk[r] = below | ((uint32_t)(__ffsll((unsigned long long)m) - 1) << 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r < rounds_n) {
+            const bool lead = (is_leader >> r) & 1u;
+            const int from = lead ? lane : (int)((rk[r] >> 16) & 63u);
+            const uint32_t p = __shfl(rk[r], from);
+            rk[r] = lead ? p : p + (rk[r] & 0xffffu);
+        }
+    }
+    __syncthreads();
+    // key offsets: exclusive over waves, then over keys (thread d owns key d)
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = s_whist[w * 256 + tid];
+        s_whist[w * 256 + tid] = tot;
+        tot += c;
+    }
+    const uint32_t start = block_excl_scan_u32<WAVES>(tot, s_tmp, nullptr);
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s_whist[w * 256 + tid] += start;
+    s_rowptr[tid] = (int32_t)start;
+    if (tid == BROWS - 1) s_rowptr[BROWS] = (int32_t)(start + tot);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r < rounds_n) {
+            const int i = wave_base + r * 64 + lane;
+            if (i < n) s_perm[whist[dg[r]] + rk[r]] = (int32_t)vv[r];
+        }
+    }
+    return tot;
+}
+
 template <typename T, int R>
 __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restrict__ src, const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ vals,
@@ -69,9 +149,7 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
     __shared__ uint32_t s_cnt[BROWS];  // contributions per destination over all chunks of the bucket
     __shared__ uint32_t s_tmp[WAVES];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t* whist = s_whist + wave * 256;
+    const int tid = threadIdx.x;
     const int G = 1 << gshift;
     const int gl = tid & (G - 1);
     const int gi = tid >> gshift, groups = THREADS >> gshift;
@@ -82,79 +160,11 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
             const bool first = cbeg == bbeg;
             const bool last = cbeg + CAP >= bend;
             const int n = (bend - cbeg < CAP) ? (bend - cbeg) : CAP;
-            __syncthreads();  // previous chunk's / bucket's readers are done with s_perm, s_rowptr, s_cnt, s_whist
+            __syncthreads();  // previous chunk's / bucket's readers are done with s_perm, s_rowptr, s_cnt
             if (first) s_cnt[tid] = 0;
-            for (int i = tid; i < WAVES * 256; i += THREADS) s_whist[i] = 0;
-            __syncthreads();
 
-            // ---- stable counting sort of (destination & 255, source position) by the 8-bit key
-            const int rounds_n = (n + THREADS - 1) / THREADS;   // rows of 64 per wave; a wave owns consecutive rows
-            const int wave_base = wave * rounds_n * 64;
-            uint32_t dg[ROUNDS], vv[ROUNDS], rk[ROUNDS];
-            uint32_t is_leader = 0;
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                dg[r] = 0; vv[r] = 0; rk[r] = 0;
-                if (r < rounds_n) {
-                    const int i = wave_base + r * 64 + lane;
-                    const bool valid = i < n;
-                    if (valid) {
-                        dg[r] = keys[cbeg + i] & (BROWS - 1);
-                        vv[r] = vals[cbeg + i];
-                    }
-                    const uint32_t d = dg[r];
-                    const uint64_t vb = __ballot(valid);
-                    uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
-                        const uint64_t bal = __ballot(xb != 0u);
-                        m_lo &= ~((uint32_t)bal ^ xb);
-                        m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
-                    }
-                    const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;   // valid lanes with my digit
-                    const uint32_t below = __popcll(m & lanes_below);
-                    if (valid && below == 0) {
-                        rk[r] = atomicAdd(&whist[d], (uint32_t)__popcll(m));  // rank of the group inside this wave
-                        is_leader |= 1u << r;
-                    } else {
-                        rk[r] = below | ((uint32_t)(__ffsll((unsigned long long)m) - 1) << 16);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                if (r < rounds_n) {
-                    const bool lead = (is_leader >> r) & 1u;
-                    const int from = lead ? lane : (int)((rk[r] >> 16) & 63u);
-                    const uint32_t p = __shfl(rk[r], from);
-                    rk[r] = lead ? p : p + (rk[r] & 0xffffu);
-                }
-            }
-            __syncthreads();
-            {   // digit offsets: exclusive over waves, then over digits (thread d owns digit d)
-                uint32_t tot = 0;
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) {
-                    const uint32_t c = s_whist[w * 256 + tid];
-                    s_whist[w * 256 + tid] = tot;
-                    tot += c;
-                }
-                const uint32_t start = block_excl_scan_u32<WAVES>(tot, s_tmp, nullptr);
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) s_whist[w * 256 + tid] += start;
-                s_rowptr[tid] = (int32_t)start;
-                if (tid == BROWS - 1) s_rowptr[BROWS] = (int32_t)(start + tot);
-                s_cnt[tid] += tot;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                if (r < rounds_n) {
-                    const int i = wave_base + r * 64 + lane;
-                    if (i < n) s_perm[whist[dg[r]] + rk[r]] = (int32_t)vv[r];
-                }
-            }
+            const uint32_t tot = sort_chunk(keys, vals, cbeg, n, s_perm, s_whist, s_rowptr, s_tmp);
+            s_cnt[tid] += tot;
             __syncthreads();
 
             // ---- segment reduction of the bucket's rows (segment.hip's loop, indices from LDS)
@@ -240,6 +250,53 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
             }
             if (last) break;
             __threadfence();  // the next chunk re-reads the rows just stored
+        }
+    }
+}
+
+// index_select, push form, from the same partition (of `index` over the table's rows): a workgroup takes a bucket of 256
+// table rows, finishes the sort on chip, loads each selected table row once and stores it to every output row that
+// selects it (select_rows_push_kernel of gather.hip with rowptr / perm in LDS). Rows are opaque 16-B lanes.
+template <int PU>
+__global__ __launch_bounds__(THREADS) void bucket_push_kernel(const char* __restrict__ in, const uint32_t* __restrict__ keys,
+                                                              const uint32_t* __restrict__ vals,
+                                                              const int32_t* __restrict__ bptr, char* __restrict__ out,
+                                                              int64_t N, int64_t NB, int64_t rowbytes, int gshift,
+                                                              int chunks) {
+    __shared__ int32_t s_perm[CAP];
+    __shared__ uint32_t s_whist[WAVES * 256];
+    __shared__ int32_t s_rowptr[BROWS + 1];
+    __shared__ uint32_t s_tmp[WAVES];
+    const int tid = threadIdx.x;
+    const int G = 1 << gshift;
+    const int gl = tid & (G - 1);
+    const int gi = tid >> gshift, groups = THREADS >> gshift;
+    for (int64_t bucket = blockIdx.x; bucket < NB; bucket += gridDim.x) {
+        const int32_t bbeg = bptr[bucket], bend = bptr[bucket + 1];
+        for (int32_t cbeg = bbeg; cbeg < bend; cbeg += CAP) {   // an unselected bucket stores nothing
+            const int n = (bend - cbeg < CAP) ? (bend - cbeg) : CAP;
+            __syncthreads();
+            sort_chunk(keys, vals, cbeg, n, s_perm, s_whist, s_rowptr, s_tmp);
+            __syncthreads();
+            for (int item = gi; item < BROWS * chunks; item += groups) {
+                const int dloc = item & (BROWS - 1);
+                const int c = item >> BSHIFT;
+                const int64_t nrow = bucket * BROWS + dloc;
+                const int64_t colb = ((int64_t)c * G + gl) * 16;
+                if (nrow >= N || colb >= rowbytes) continue;
+                const int32_t beg = s_rowptr[dloc], end = s_rowptr[dloc + 1];
+                if (beg == end) continue;
+                const u32x4 v = load16<true>(in + nrow * rowbytes + colb);
+                char* outb = out + colb;
+                for (int32_t j = beg; j < end; j += PU) {
+                    int32_t e[PU];
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) e[u] = (j + u < end) ? s_perm[j + u] : -1;
+#pragma unroll
+                    for (int u = 0; u < PU; ++u)
+                        if (e[u] >= 0) store16<true>(outb + (int64_t)e[u] * rowbytes, v);
+                }
+            }
         }
     }
 }
@@ -368,6 +425,35 @@ extern "C" int gnnops_bucket_reduce(const void* src, const void* workspace, void
         case GNNOPS_F16: return dispatch_bucket<__half>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream);
         default: return dispatch_bucket<__hip_bfloat16>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream);
     }
+}
+
+// index_select(input [N, K], index [E]) -> out [E, K] from a workspace gnnops_bucket_partition filled for (index, E, N):
+// every selected input row is read once. Rows are K * elem_bytes bytes, a multiple of 16, 16-B aligned.
+extern "C" int gnnops_bucket_select(const void* input, const void* workspace, void* out, int64_t N, int64_t K, int64_t E,
+                                    int elem_bytes, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "bucket_select: negative size");
+    const int64_t rowbytes = K * elem_bytes;
+    GNNOPS_REQUIRE(rowbytes > 0 && rowbytes % 16 == 0 && (uintptr_t)input % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+                       oneshot_shape_ok(E, N),
+                   GNNOPS_EUNSUPPORTED, "bucket_select: shape outside the bucketed form (E=%lld K=%lld N=%lld)", (long long)E,
+                   (long long)K, (long long)N);
+    GNNOPS_REQUIRE(input && workspace && out, GNNOPS_EINVAL, "bucket_select: null pointer");
+    const Layout l = layout(E, N);
+    const char* w = (const char*)workspace;
+    const int last = (partition_passes(N) - 1) & 1;
+    const uint32_t* keys = (const uint32_t*)(w + (last ? l.keys_b : l.keys_a));
+    const uint32_t* vals = (const uint32_t*)(w + (last ? l.vals_b : l.vals_a));
+    const int32_t* bptr = (const int32_t*)(w + l.bptr);
+    const int64_t NB = gnnops_cdiv(N, BROWS);
+    const int64_t lanes = rowbytes / 16;
+    int gshift = 0;
+    while ((1 << gshift) < lanes && gshift < 6) ++gshift;
+    const int chunks = (int)gnnops_cdiv(lanes, (int64_t)1 << gshift);
+    const int grid = gnnops_grid_cap(NB, 256 * 16);
+    hipLaunchKernelGGL((bucket_push_kernel<8>), dim3(grid), dim3(THREADS), 0, stream, (const char*)input, keys, vals, bptr,
+                       (char*)out, N, NB, rowbytes, gshift, chunks);
+    return gnnops_check_launch("bucket_select");
 }
 
 // Both stages in one call — what a scatter with no plan to reuse runs. GNNOPS_EUNSUPPORTED (take the plan path instead)

@@ -380,6 +380,15 @@ def index_select(input, dim, index, plan=None):
     row_bytes = K * eb
     if (plan is None and row_bytes % 16 == 0 and N * row_bytes * B >= _PUSH_MIN_TABLE_BYTES
             and E >= _PUSH_MIN_REUSE * N and input.data_ptr() % 16 == 0):
+        if B == 1 and not _plan_cache_enabled and 256 < N < 2 ** 31 and E < 2 ** 31:
+            # push form with no plan to keep: partition by bucket, finish the sort on chip inside the copy (bucket.hip)
+            ws_bytes = L.gnnops_bucket_workspace_bytes(E, N)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
+            with torch.cuda.device(input.device):
+                check(L.gnnops_bucket_partition(index.data_ptr(), E, N, ws.data_ptr(), ws_bytes, _stream()), "bucket_partition")
+                check(L.gnnops_bucket_select(input.data_ptr(), ws.data_ptr(), out.data_ptr(), N, K, E, eb, _stream()),
+                      "bucket_select")
+            return out
         plan = get_plan(index, N)
     with torch.cuda.device(input.device):
         if plan is not None:

@@ -110,6 +110,11 @@ int gnnops_bucket_partition(const int64_t* index, int64_t E, int64_t N, void* wo
 int gnnops_bucket_reduce(const void* src, const void* workspace, void* out, int64_t* arg_out,
                          int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
                          gnnops_stream_t stream);
+/* torch.index_select(input [N,K], 0, index [E]) -> out [E,K] (benchmark_native_index_select.py:14), push form, from a
+ * workspace gnnops_bucket_partition filled for (index, E, N): each selected input row is read once and stored to every
+ * output row that selects it. Rows must be a multiple of 16 bytes and 16-B aligned. */
+int gnnops_bucket_select(const void* input, const void* workspace, void* out, int64_t N, int64_t K, int64_t E,
+                         int elem_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Element-wise scatter, layout F (index has the shape of src) — what the reference scripts build

@@ -122,3 +122,43 @@ def test_oneshot_config2_slice(gnnops, no_cache):
     assert torch.equal(a, gnnops.scatter_add(src, idx, 0, dim_size=N))
     mn2, am2 = gnnops.scatter_min(src, idx, 0, dim_size=N)
     assert torch.equal(mn, mn2) and torch.equal(am, am2)
+
+
+def _bucket_select(gnnops, table, idx):
+    """gnnops_bucket_partition + gnnops_bucket_select through the C ABI (the size heuristic of ops.index_select aside)."""
+    from gnnops import _lib
+    from gnnops.ops import _stream
+
+    L = _lib.load()
+    N, K = table.shape
+    E = idx.numel()
+    out = torch.empty(E, K, dtype=table.dtype, device=table.device)
+    ws_bytes = L.gnnops_bucket_workspace_bytes(E, N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
+    _lib.check(L.gnnops_bucket_partition(idx.data_ptr(), E, N, ws.data_ptr(), ws_bytes, _stream()), "bucket_partition")
+    _lib.check(L.gnnops_bucket_select(table.data_ptr(), ws.data_ptr(), out.data_ptr(), N, K, E, table.element_size(),
+                                      _stream()), "bucket_select")
+    return out
+
+
+@pytest.mark.parametrize("kind", ["uniform", "skew", "front"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.int64])
+@pytest.mark.parametrize("E,N,K", [(5000, 1000, 128), (100000, 300, 16), (3000, 257, 264), (70000, 70000, 32), (1, 1000, 8)])
+def test_bucket_select(gnnops, kind, dt, E, N, K):
+    g = torch.Generator().manual_seed(E + N)
+    table = (torch.rand(N, K, generator=g) * 1000).to(dt).cuda()
+    idx = _index(kind, E, N, g).cuda()
+    assert torch.equal(_bucket_select(gnnops, table, idx), table[idx])
+
+
+def test_index_select_oneshot_push(gnnops, no_cache):
+    """A table beyond the push threshold (>= 1 GiB, E >= 3 N): ops.index_select takes the bucketed push form when the
+    plan cache is off, the planned push form when it is on; both equal torch's gather."""
+    N, K, E = 2_200_000, 128, 7_000_000
+    g = torch.Generator(device="cuda").manual_seed(2)
+    table = torch.rand(N, K, generator=g, device="cuda")
+    idx = torch.randint(0, N, (E,), generator=g, device="cuda")
+    a = gnnops.index_select(table, 0, idx)
+    assert torch.equal(a, table[idx])
+    gnnops.set_plan_cache(True)
+    assert torch.equal(gnnops.index_select(table, 0, idx), a)

@@ -34,3 +34,10 @@ for rep in range(3):
         a = timed(lambda: gnnops.scatter(src, idx, 0, dim_size=N, reduce=r))
         b = timed(lambda: plan_path(r))
         print(f"{r:5s} oneshot {a:7.3f} ms   plan+segment {b:7.3f} ms", flush=True)
+
+table = torch.rand(N, D, generator=g, device="cuda")
+for rep in range(3):
+    gnnops.set_plan_cache(False)
+    a = timed(lambda: gnnops.index_select(table, 0, idx))
+    b = timed(lambda: gnnops.index_select(table, 0, idx, plan=gnnops.Plan(idx, N)))
+    print(f"index_select oneshot {a:7.3f} ms   plan+push {b:7.3f} ms", flush=True)
