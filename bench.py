@@ -56,9 +56,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cut", type=float, default=0.1,
+    ap.add_argument("--cut", type=float, default=None,
                     help="N>1 only: fraction of each rank's edges whose destination another rank owns (edge cut of the "
-                         "partition; the rest fall uniformly in the rank's own rows). (G-1)/G = unpartitioned uniform graph")
+                         "partition; the rest fall uniformly in the rank's own rows). Default: 1/70 per peer, i.e. "
+                         "(G-1)/70 — every pair of partitions shares the same boundary, 10 %% in total at G=8. "
+                         "(G-1)/G = an unpartitioned uniform random graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-ops", action="store_true", help="skip the per-op table (scatter_min/max/mean, index_select, index_add_)")
     args = ap.parse_args()
@@ -87,6 +89,8 @@ def main():
 
     Nloc, E, D, _ = WORKLOADS[args.workload]
     Ntot = Nloc * world
+    if args.cut is None:
+        args.cut = (world - 1) / 70.0
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
     src = torch.rand(E, D, generator=gen, device=dev, dtype=torch.float32)
 

@@ -176,6 +176,9 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
                 const int64_t col = ((int64_t)chunk * G + gl) * VEC;
                 if (nrow >= N || col >= K) continue;
                 const int32_t beg = s_rowptr[dloc], end = s_rowptr[dloc + 1];
+                // nothing to fold in and the row already holds the running value: leave it (unless this visit must still
+                // write an arg row, zero-fill an empty min / max group or divide a mean)
+                if (beg == end && from_out && !(IS_ARG && (arg_out || (last && !init_from_out))) && !(is_mean && last)) continue;
                 const T* srcb = src + col;
                 const int64_t oidx = nrow * K + col;
 
@@ -348,8 +351,20 @@ inline Layout layout(int64_t E, int64_t N) {
     return l;
 }
 
-// Which ping-pong buffer holds the partitioned (key, position) pairs: fixed by N.
-inline int partition_passes(int64_t N) { return (key_bits(N) - BSHIFT + 7) / 8; }  // LSD passes over bits [BSHIFT, bits)
+// Keys are destinations in [0, N) plus one sentinel, the first multiple of 256 at or past N ("not mine": positions the
+// windowed partition drops land in a bucket of their own behind the last real one). LSD passes cover bits [BSHIFT, bits)
+// of the sentinel; their count also fixes which ping-pong buffer holds the partitioned (key, position) pairs.
+inline int64_t sentinel_key(int64_t N) { return gnnops_cdiv(N, BROWS) * BROWS; }
+inline int partition_passes(int64_t N) { return (key_bits(sentinel_key(N) + 1) - BSHIFT + 7) / 8; }
+
+// key[e] = index[e] - lo if that lies in [0, N), else the sentinel.
+__global__ void window_keys_kernel(const int64_t* __restrict__ index, uint32_t* __restrict__ keys, int64_t E, int64_t lo,
+                                   int64_t N, uint32_t sentinel) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = (uint64_t)(index[e] - lo);
+        keys[e] = d < (uint64_t)N ? (uint32_t)d : sentinel;
+    }
+}
 
 inline bool oneshot_shape_ok(int64_t E, int64_t N) {
     return N > BROWS && E > 0 && E < ((int64_t)1 << 31) && N < ((int64_t)1 << 31);
@@ -362,17 +377,15 @@ extern "C" size_t gnnops_bucket_workspace_bytes(int64_t E, int64_t N) {
     return layout(E, N).total;
 }
 
-// Stage 1: group the E positions by bucket = index >> 8, in position order inside a bucket, and find the bucket
-// boundaries. The workspace then IS the partition: gnnops_bucket_reduce may be called on it any number of times.
-extern "C" int gnnops_bucket_partition(const int64_t* index, int64_t E, int64_t N, void* workspace, size_t workspace_bytes,
-                                       gnnops_stream_t s) {
-    hipStream_t stream = (hipStream_t)s;
-    GNNOPS_REQUIRE(E >= 0 && N >= 0, GNNOPS_EINVAL, "bucket_partition: negative size");
-    GNNOPS_REQUIRE(oneshot_shape_ok(E, N), GNNOPS_EUNSUPPORTED,
-                   "bucket_partition: shape outside the bucketed form (E=%lld N=%lld)", (long long)E, (long long)N);
-    GNNOPS_REQUIRE(index, GNNOPS_EINVAL, "bucket_partition: null pointer");
+namespace {
+int partition_impl(const int64_t* index, int64_t E, int64_t lo, int64_t N, bool window, void* workspace,
+                   size_t workspace_bytes, hipStream_t stream, const char* what) {
+    GNNOPS_REQUIRE(E >= 0 && N >= 0, GNNOPS_EINVAL, "%s: negative size", what);
+    GNNOPS_REQUIRE(oneshot_shape_ok(E, N), GNNOPS_EUNSUPPORTED, "%s: shape outside the bucketed form (E=%lld N=%lld)", what,
+                   (long long)E, (long long)N);
+    GNNOPS_REQUIRE(index, GNNOPS_EINVAL, "%s: null pointer", what);
     const Layout l = layout(E, N);
-    GNNOPS_REQUIRE(workspace && workspace_bytes >= l.total, GNNOPS_EWORKSPACE, "bucket_partition: workspace %zu < %zu",
+    GNNOPS_REQUIRE(workspace && workspace_bytes >= l.total, GNNOPS_EWORKSPACE, "%s: workspace %zu < %zu", what,
                    workspace_bytes, l.total);
     char* w = (char*)workspace;
     uint32_t* kbuf[2] = {(uint32_t*)(w + l.keys_a), (uint32_t*)(w + l.keys_b)};
@@ -382,19 +395,57 @@ extern "C" int gnnops_bucket_partition(const int64_t* index, int64_t E, int64_t 
     int32_t* bptr = (int32_t*)(w + l.bptr);
     const int tiles = (int)gnnops_cdiv(E, sortengine::TILE);
     const int passes = partition_passes(N);  // >= 1 because N > 256
+    if (window) {  // keys_b is free until pass 1 writes it, and pass 0 is the only reader of the windowed keys
+        const int grid = gnnops_grid_cap(gnnops_cdiv(E, 256), 256 * 16);
+        hipLaunchKernelGGL(window_keys_kernel, dim3(grid), dim3(256), 0, stream, index, kbuf[1], E, lo, N,
+                           (uint32_t)sentinel_key(N));
+    }
     const uint32_t* kin = nullptr;
     const uint32_t* vin = nullptr;
     for (int p = 0; p < passes; ++p) {
         uint32_t* kout = kbuf[p & 1];
         uint32_t* vout = vbuf[p & 1];
-        const int rc = (p == 0) ? sortengine::pass_first_i64(index, kout, vout, E, BSHIFT, tile_hist, digit_total, tiles, stream)
-                                : sortengine::pass_u32(kin, vin, kout, vout, E, BSHIFT + 8 * p, tile_hist, digit_total, tiles, stream);
+        int rc;
+        if (p == 0)
+            rc = window ? sortengine::pass_first_u32(kbuf[1], kout, vout, E, BSHIFT, tile_hist, digit_total, tiles, stream)
+                        : sortengine::pass_first_i64(index, kout, vout, E, BSHIFT, tile_hist, digit_total, tiles, stream);
+        else
+            rc = sortengine::pass_u32(kin, vin, kout, vout, E, BSHIFT + 8 * p, tile_hist, digit_total, tiles, stream);
         if (rc != GNNOPS_OK) return rc;
         kin = kout; vin = vout;
     }
     const int64_t NB = gnnops_cdiv(N, BROWS);
     hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)gnnops_cdiv(NB + 1, 256)), dim3(256), 0, stream, kin, E, NB, bptr);
-    return gnnops_check_launch("bucket_partition");
+    return gnnops_check_launch(what);
+}
+}  // namespace
+
+// Stage 1: group the E positions by bucket = index >> 8, in position order inside a bucket, and find the bucket
+// boundaries. The workspace then IS the partition: gnnops_bucket_reduce / gnnops_bucket_select may be called on it any
+// number of times. Every index[e] must lie in [0, N).
+extern "C" int gnnops_bucket_partition(const int64_t* index, int64_t E, int64_t N, void* workspace, size_t workspace_bytes,
+                                       gnnops_stream_t s) {
+    return partition_impl(index, E, 0, N, false, workspace, workspace_bytes, (hipStream_t)s, "bucket_partition");
+}
+
+// Windowed stage 1 (destination-partitioned scatter, gnnops/dist.py): positions with index[e] in [lo, lo + N) are
+// partitioned under the local id index[e] - lo; all others are set aside, in position order, behind the last bucket:
+// they are vals[bptr[NB] .. E) of the layout below and no reduce / select touches them.
+extern "C" int gnnops_bucket_partition_window(const int64_t* index, int64_t E, int64_t lo, int64_t N, void* workspace,
+                                              size_t workspace_bytes, gnnops_stream_t s) {
+    return partition_impl(index, E, lo, N, true, workspace, workspace_bytes, (hipStream_t)s, "bucket_partition_window");
+}
+
+// Byte offsets, inside a partitioned workspace, of the (key u32[E], position u32[E]) pairs and of bptr int32[NB + 1]
+// (NB = ceil(N / 256); bucket b holds pairs bptr[b] .. bptr[b+1]).
+extern "C" int gnnops_bucket_layout(int64_t E, int64_t N, size_t* keys_offset, size_t* vals_offset, size_t* bptr_offset) {
+    GNNOPS_REQUIRE(E >= 0 && N >= 0 && keys_offset && vals_offset && bptr_offset, GNNOPS_EINVAL, "bucket_layout: bad argument");
+    const Layout l = layout(E, N);
+    const int last = (partition_passes(N) - 1) & 1;
+    *keys_offset = last ? l.keys_b : l.keys_a;
+    *vals_offset = last ? l.vals_b : l.vals_a;
+    *bptr_offset = l.bptr;
+    return GNNOPS_OK;
 }
 
 // Stage 2: out[n, :] = reduce over { src[e, :] : index[e] == n } in ascending e, from a workspace gnnops_bucket_partition

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
         const int64_t col = ((int64_t)chunk * G + gl) * VEC;
         if (col >= K) continue;
         const int32_t beg = rowptr[n], end = rowptr[n + 1];
+        if (beg == end && init_from_out && !(IS_ARG && arg_out)) continue;  // nothing to fold in: the out row stays as it is
         const T* srcb = src + (b * E) * K + col;
         const int64_t oidx = (b * N + n) * K + col;
 

@@ -25,6 +25,8 @@ SIGNATURES = {
     "gnnops_segment_reduce": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp]),
     "gnnops_bucket_workspace_bytes": (_sz, [_i64, _i64]),
     "gnnops_bucket_partition": (_ci, [_vp, _i64, _i64, _vp, _sz, _vp]),
+    "gnnops_bucket_partition_window": (_ci, [_vp, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "gnnops_bucket_layout": (_ci, [_i64, _i64, _vp, _vp, _vp]),
     "gnnops_bucket_reduce": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _ci, _ci, _vp]),
     "gnnops_bucket_select": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp]),
     "gnnops_scatter_rows_oneshot": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),

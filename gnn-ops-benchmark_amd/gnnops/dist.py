@@ -5,13 +5,15 @@ with GLOBAL destination ids anywhere in [0, n_total)); destination rows are part
 (rank g owns rows [g*n_total/G, (g+1)*n_total/G)). The path has exactly one exchange step, and two forms of it:
 
 ``exchange="sparse"`` (default) — a reduce-scatter of only what is there:
-  1. one plan (stable inverted index) over this rank's edges;
-  2. edges whose destination another rank owns are reduced per DISTINCT destination into compact
+  1. one windowed partition of this rank's edges: those whose destination it owns are bucketed under their local id
+     (stage 1 of the single-GPU one-shot scatter), all others come out set aside in source order;
+  2. only the set-aside edges are sorted by destination and reduced per DISTINCT destination into compact
      (id, row) lists, grouped by owner (ids ascend, so the groups are contiguous slices);
   3. ONE all-to-all-v of those lists (RCCL over xGMI; `torch.distributed` backend "nccl" is RCCL on ROCm) —
      issued asynchronously, while
   4. the edges this rank owns itself are reduced straight into its slab;
   5. the received rows are scatter-reduced into the slab.
+  (fp32 sums; other dtypes / reduces build one full plan over the global ids instead of 1-2, same exchange.)
   Bytes on the wire per rank = (#distinct remote destinations touched) x (row + 8), i.e. proportional to the
   edge cut of the partition, not to n_total. RCCL has no sparse reduce-scatter; this composes one from
   all_to_all_single and the local segment reduce.
@@ -52,8 +54,7 @@ class HipLocal:
         ``out`` when one is passed), else the compact pair (ids_own - lo, rows_own) — so the caller can start the
         exchange first and overlap the two.
         """
-        from . import _lib
-        from .ops import REDUCE_CODE, Plan, _dtype_code, _require_gpu, _stream, check
+        from .ops import _require_gpu
 
         _require_gpu(src, index)
         if src.dim() != 2 or index.dim() != 1 or index.numel() != src.size(0):
@@ -61,21 +62,90 @@ class HipLocal:
         if src.size(0) >= 2 ** 31 or n_total >= 2 ** 31:
             raise NotImplementedError("sharded_scatter(exchange='sparse'): E and n_total must be < 2^31")
         src = src.contiguous()
+        index = index.contiguous()
+        D = src.size(1)
+        windowed = (own_dense and src.dtype == torch.float32 and hi - lo > 256 and src.size(0) > 0
+                    and D % 4 == 0 and src.data_ptr() % 16 == 0)
+        if windowed:
+            return self._split_windowed(src, index, n_total, lo, hi, reduce)
+        return self._split_planned(src, index, n_total, lo, hi, reduce, own_dense)
+
+    @staticmethod
+    def _seg(src, crow, perm, n_rows, out, reduce):
+        """out[i] = reduce over src[perm[crow[i] : crow[i+1]]] (crow int32: absolute positions into perm)."""
+        from . import _lib
+        from .ops import REDUCE_CODE, _dtype_code, _stream, check
+
+        if n_rows == 0:
+            return
         E, D = src.shape
+        with torch.cuda.device(src.device):
+            check(_lib.load().gnnops_segment_reduce(src.data_ptr(), crow.data_ptr(), perm.data_ptr(), out.data_ptr(), None, 1,
+                                                    E, D, n_rows, _dtype_code(src, "sharded_scatter"),
+                                                    REDUCE_CODE["sum" if reduce == "add" else reduce], 0, _stream()),
+                  "segment_reduce")
+
+    def _split_windowed(self, src, index, n_total, lo, hi, reduce):
+        """fp32 sums: ONE windowed partition serves both sides. Positions whose destination lies in [lo, hi) are bucketed
+        under their local id and reduced straight into the slab (bucket.hip, the one-shot form of the single-GPU op);
+        all other positions come out of the partition set aside in order, and only those (a `cut` fraction of E) are
+        sorted by destination and reduced per distinct destination."""
+        import ctypes
+
+        from . import _lib
+        from .ops import _stream, check
+        from .sparse import sort
+
         L = _lib.load()
-        dt = _dtype_code(src, "sharded_scatter")
-        rcode = REDUCE_CODE["sum" if reduce == "add" else reduce]
+        E, D = src.shape
+        n_loc = hi - lo
+        dev = src.device
+        ws_bytes = L.gnnops_bucket_workspace_bytes(E, n_loc)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(L.gnnops_bucket_partition_window(index.data_ptr(), E, lo, n_loc, ws.data_ptr(), ws_bytes, _stream()),
+                  "bucket_partition_window")
+        ko, vo, bo = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        check(L.gnnops_bucket_layout(E, n_loc, ctypes.byref(ko), ctypes.byref(vo), ctypes.byref(bo)), "bucket_layout")
+        nb = (n_loc + 255) // 256
+        bptr = ws[bo.value: bo.value + 4 * (nb + 1)].view(torch.int32)
+        first_remote = int(bptr[nb].item())                       # positions set aside start here
+        remote_pos = ws[vo.value + 4 * first_remote: vo.value + 4 * E].view(torch.int32)   # ascending (stable)
+        if remote_pos.numel():
+            rpos64 = remote_pos.long()
+            sorted_ids, order = sort(index[rpos64].to(torch.int32))          # stable: source order inside a destination
+            ids32, counts = torch.unique_consecutive(sorted_ids, return_counts=True)
+            crow = torch.zeros(ids32.numel() + 1, dtype=torch.int32, device=dev)
+            crow[1:] = torch.cumsum(counts, 0)
+            perm = rpos64[order].to(torch.int32)
+            ids = ids32.long()
+            rows = torch.empty((ids.numel(), D), dtype=src.dtype, device=dev)
+            self._seg(src, crow, perm, ids.numel(), rows, reduce)
+        else:
+            ids = torch.empty(0, dtype=torch.int64, device=dev)
+            rows = torch.empty((0, D), dtype=src.dtype, device=dev)
+
+        def own(out=None):
+            slab = out if out is not None else torch.empty((n_loc, D), dtype=src.dtype, device=dev)
+            with torch.cuda.device(dev):
+                check(L.gnnops_bucket_reduce(src.data_ptr(), ws.data_ptr(), slab.data_ptr(), None, E, D, n_loc, _lib.F32,
+                                             _lib.SUM, 0, _stream()), "bucket_reduce")
+            return slab
+
+        return own, ids, rows
+
+    def _split_planned(self, src, index, n_total, lo, hi, reduce, own_dense):
+        """Any dtype / reduce: one full plan over the global ids; its row pointer restricted to touched rows is itself a
+        CSR row pointer over perm (untouched rows are empty), so compact reductions are plain segment reductions."""
+        from .ops import Plan
+
+        E, D = src.shape
+        dev = src.device
         plan = Plan(index, n_total)
         rowptr, perm = plan.rowptr, plan.perm
-        dev = src.device
 
         def seg(rp, n_rows, out):
-            # rows of `out` = reduce over perm[rp[i] : rp[i+1]] (absolute positions: any slice of a rowptr works)
-            if n_rows == 0:
-                return
-            with torch.cuda.device(dev):
-                check(L.gnnops_segment_reduce(src.data_ptr(), rp.data_ptr(), perm.data_ptr(), out.data_ptr(), None, 1, E,
-                                              D, n_rows, dt, rcode, 0, _stream()), "segment_reduce")
+            self._seg(src, rp, perm, n_rows, out, reduce)
 
         touched = rowptr[1:] != rowptr[:-1]
         own_touched = None if own_dense else touched[lo:hi].nonzero().squeeze(1)

@@ -107,6 +107,14 @@ int gnnops_scatter_rows_oneshot(const void* src, const int64_t* index, void* out
 size_t gnnops_bucket_workspace_bytes(int64_t E, int64_t N);
 int gnnops_bucket_partition(const int64_t* index, int64_t E, int64_t N, void* workspace, size_t workspace_bytes,
                             gnnops_stream_t stream);
+/* Windowed partition (the per-GPU step of the destination-partitioned scatter, BASELINE config 5): positions with
+ * index[e] in [lo, lo+N) are partitioned under the local id index[e]-lo; the others are set aside in position order
+ * behind the last bucket (pairs bptr[NB] .. E of the layout) and are ignored by reduce / select. */
+int gnnops_bucket_partition_window(const int64_t* index, int64_t E, int64_t lo, int64_t N, void* workspace,
+                                   size_t workspace_bytes, gnnops_stream_t stream);
+/* Byte offsets inside a partitioned workspace: keys u32[E] (local id, sentinel ceil(N/256)*256 for set-aside positions),
+ * positions u32[E], bptr int32[ceil(N/256)+1]. Host-only, no device work. */
+int gnnops_bucket_layout(int64_t E, int64_t N, size_t* keys_offset, size_t* vals_offset, size_t* bptr_offset);
 int gnnops_bucket_reduce(const void* src, const void* workspace, void* out, int64_t* arg_out,
                          int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
                          gnnops_stream_t stream);
