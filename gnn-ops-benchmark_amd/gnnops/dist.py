@@ -171,6 +171,54 @@ class HipLocal:
 
         return own, ids, rows
 
+    def spmm_split(self, row, col, value, mat, n_total, lo, hi):
+        """Source-partitioned SpMM: this rank's nonzeros (global output row, LOCAL column into its slab `mat` [K_g, D],
+        value or None) multiplied out per output row and split by ownership, like `split` with own_dense=True:
+        returns (own, ids, rows). One plan over the rows; a row pointer restricted to touched rows is a CSR row pointer,
+        so both the own slab and the compact remote rows are plain gnnops_spmm launches over slices of it."""
+        from . import _lib
+        from .ops import Plan, _dtype_code, _require_gpu, _stream, check
+
+        _require_gpu(row, col, mat, value)
+        if row.dim() != 1 or col.shape != row.shape or mat.dim() != 2:
+            raise ValueError("sharded_spmm: row / col must be 1-D of equal length, mat 2-D")
+        if row.numel() >= 2 ** 31 or n_total >= 2 ** 31:
+            raise NotImplementedError("sharded_spmm: nnz and n_total must be < 2^31")
+        if value is not None and value.dtype != mat.dtype:
+            raise RuntimeError("sharded_spmm: value and mat must have the same dtype")
+        row, col, mat = row.contiguous(), col.contiguous(), mat.contiguous()
+        value = value.contiguous() if value is not None else None
+        L = _lib.load()
+        dt = _dtype_code(mat, "sharded_spmm")
+        D = mat.size(1)
+        dev = mat.device
+        plan = Plan(row, n_total)
+        rowptr, perm = plan.rowptr, plan.perm
+
+        def mm(rp, n_rows, out):
+            if n_rows == 0:
+                return
+            with torch.cuda.device(dev):
+                check(L.gnnops_spmm(rp.data_ptr(), perm.data_ptr(), col.data_ptr(),
+                                    value.data_ptr() if value is not None else None, mat.data_ptr(), out.data_ptr(), n_rows,
+                                    D, row.numel(), mat.size(0), dt, _stream()), "spmm")
+
+        touched = rowptr[1:] != rowptr[:-1]
+        touched[lo:hi] = False
+        ids = touched.nonzero().squeeze(1)
+        n_lo = int(torch.searchsorted(ids, lo).item())
+        crow = torch.cat([rowptr[ids[:n_lo]], rowptr[lo:lo + 1], rowptr[ids[n_lo:]], rowptr[n_total:n_total + 1]])
+        rows = torch.empty((ids.numel(), D), dtype=mat.dtype, device=dev)
+        mm(crow[: n_lo + 1], n_lo, rows[:n_lo])
+        mm(crow[n_lo + 1:], ids.numel() - n_lo, rows[n_lo:])
+
+        def own(out=None):
+            slab = out if out is not None else torch.empty((hi - lo, D), dtype=mat.dtype, device=dev)
+            mm(rowptr[lo:hi + 1], hi - lo, slab)
+            return slab
+
+        return own, ids, rows
+
     def accumulate(self, slab, rows, ids_local, reduce):
         """slab[ids_local[j]] (+)= rows[j], in place (sum only: the slab's untouched rows hold the neutral 0)."""
         from .ops import scatter
@@ -273,3 +321,33 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
     if reduce in ("min", "max"):
         out_slab = torch.where(torch.isinf(out_slab), torch.zeros_like(out_slab), out_slab)
     return out_slab
+
+
+def sharded_spmm(index_local, value_local, n_total, matrix_local, group=None, out_slab=None, local=None):
+    """Source-partitioned SpMM across the GPUs of one node (SURVEY.md §8e "column(src)-partitioned A with B slabs").
+
+    Rank g holds the slab ``matrix_local`` [K_g, D] of the dense operand (the features of the source nodes it owns) and
+    the nonzeros whose column falls in that slab: ``index_local`` [2, nnz_g] = (GLOBAL output row, LOCAL column),
+    ``value_local`` [nnz_g] or None. Returns the slab of ``A @ B`` this rank owns (rows [g*n_total/G, (g+1)*n_total/G)).
+    Same single exchange as sharded_scatter(exchange="sparse"): partial output rows for rows other ranks own travel as
+    compact (id, row) lists in one all-to-all-v while the own slab is multiplied; the received rows are added in.
+    (Destination-partitioned A with a replicated B needs no collective: that is a plain local ``gnnops.spmm``.)
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = owned_rows(n_total, rank, world)
+    if local is None:
+        local = HipLocal()
+    if index_local.dim() != 2 or index_local.size(0) != 2:
+        raise ValueError("sharded_spmm: index_local must be [2, nnz]")
+    own, ids, rows = local.spmm_split(index_local[0], index_local[1], value_local, matrix_local, n_total, lo, hi)
+    recv_ids, recv_rows, works = _exchange(ids, rows, hi - lo, rank, world, group)
+    direct = out_slab is not None and out_slab.is_contiguous() and out_slab.dtype == matrix_local.dtype
+    slab = own(out_slab) if direct else own()
+    for w in works:
+        w.wait()
+    slab = local.accumulate(slab, recv_rows, recv_ids - lo, "sum")
+    if out_slab is not None and slab is not out_slab:
+        out_slab.copy_(slab)
+        return out_slab
+    return slab

@@ -50,6 +50,27 @@ class OracleLocal:
 
         return own, ids, rows
 
+    def spmm_split(self, row, col, value, mat, n_total, lo, hi):
+        from oracle import oracle
+
+        r, c = row.numpy(), col.numpy()
+        uniq, inv = np.unique(r, return_inverse=True)
+        red = oracle.spmm(np.stack([inv.astype(np.int64), c]), None if value is None else value.numpy(), len(uniq),
+                          mat.shape[0], mat.numpy())
+        remote = (uniq < lo) | (uniq >= hi)
+        ids = torch.from_numpy(uniq[remote].astype(np.int64))
+        rows = torch.from_numpy(np.ascontiguousarray(red[remote]))
+        own_ids = torch.from_numpy((uniq[~remote] - lo).astype(np.int64))
+        own_rows = torch.from_numpy(np.ascontiguousarray(red[~remote]))
+
+        def own(out=None):
+            slab = out if out is not None else torch.empty((hi - lo, mat.shape[1]), dtype=mat.dtype)
+            slab.zero_()
+            slab[own_ids] = own_rows
+            return slab
+
+        return own, ids, rows
+
     def accumulate(self, slab, rows, ids_local, reduce):
         slab.index_add_(0, ids_local, rows)
         return slab
@@ -69,6 +90,16 @@ def make_inputs(rank, world, n_total, e_local, d):
     return src, idx
 
 
+def make_spmm_inputs(rank, world, n_total, nnz_local, k_local, d):
+    """Source-partitioned operand of rank `rank`: nonzeros (global row, local column), values, dense slab [k_local, d]."""
+    g = torch.Generator().manual_seed(500 + rank)
+    row = torch.randint(0, n_total, (nnz_local,), generator=g)
+    col = torch.randint(0, k_local, (nnz_local,), generator=g)
+    val = torch.rand(nnz_local, generator=g) * 2 - 1
+    mat = torch.rand(k_local, d, generator=g) * 2 - 1
+    return torch.stack([row, col]), val, mat
+
+
 def run(rank, world, init_file, n_total, e_local, d, out_dir):
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     try:
@@ -84,6 +115,11 @@ def run(rank, world, init_file, n_total, e_local, d, out_dir):
         got = sharded_scatter(src, idx, n_total, "sum", local=OracleLocal(), out_slab=slab)
         assert got is slab
         res["sparse_sum_out"] = slab.numpy()
+        from gnnops.dist import sharded_spmm
+
+        idx2, val, mat = make_spmm_inputs(rank, world, n_total, e_local, 40, d)
+        res["spmm"] = sharded_spmm(idx2, val, n_total, mat, local=OracleLocal()).numpy()
+        res["spmm_noval"] = sharded_spmm(idx2, None, n_total, mat, local=OracleLocal()).numpy()
         lo, hi = owned_rows(n_total, rank, world)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi, **res)
     finally:

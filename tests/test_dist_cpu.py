@@ -46,6 +46,18 @@ def test_sharded_scatter_two_ranks():
                     np.testing.assert_allclose(got["sparse_" + r], exp[lo:hi], rtol=1e-5, atol=1e-5, err_msg=r)
             np.testing.assert_allclose(got["sparse_sum_out"], got["sparse_sum"], rtol=0, atol=0)
             assert (got["sparse_sum"][5 - lo] == 0).all() if lo <= 5 < hi else True
+        # source-partitioned SpMM: the global operand is the ranks' column blocks side by side
+        parts = [dist_worker.make_spmm_inputs(r, world, n_total, e_local, 40, d) for r in range(world)]
+        gidx = np.concatenate([np.stack([p[0][0].numpy(), p[0][1].numpy() + 40 * r]) for r, p in enumerate(parts)], axis=1)
+        gval = np.concatenate([p[1].numpy() for p in parts])
+        gmat = np.concatenate([p[2].numpy() for p in parts], axis=0)
+        exp = oracle.spmm(gidx, gval, n_total, 40 * world, gmat)
+        exp1 = oracle.spmm(gidx, None, n_total, 40 * world, gmat)
+        for rank in range(world):
+            got = np.load(os.path.join(tmp, f"rank{rank}.npz"))
+            lo, hi = int(got["lo"]), int(got["hi"])
+            np.testing.assert_allclose(got["spmm"], exp[lo:hi], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(got["spmm_noval"], exp1[lo:hi], rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.timeout(180)

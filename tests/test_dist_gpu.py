@@ -59,6 +59,30 @@ def test_split_matches_oracle(local, oracle, reduce, E, n_total, D):
         assert np.array_equal(own_rows.cpu().numpy(), exp[lo:hi][touched[lo:hi]])
 
 
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+@pytest.mark.parametrize("with_value", [True, False])
+def test_spmm_split_matches_oracle(local, oracle, with_value, dname):
+    from helpers import TORCH_DT, to_np
+
+    nnz, n_total, k_local, D = 6000, 900, 70, 64
+    g = torch.Generator().manual_seed(21)
+    row = torch.randint(0, n_total, (nnz,), generator=g)
+    row[row % 5 == 1] = 3
+    col = torch.randint(0, k_local, (nnz,), generator=g)
+    val = (torch.rand(nnz, generator=g) * 2 - 1).to(TORCH_DT[dname]) if with_value else None
+    mat = (torch.rand(k_local, D, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    lo, hi = 300, 600
+    own, ids, rows = local.spmm_split(row.cuda(), col.cuda(), None if val is None else val.cuda(), mat.cuda(), n_total, lo, hi)
+    exp = oracle.spmm(np.stack([row.numpy(), col.numpy()]), None if val is None else to_np(val), n_total, k_local, to_np(mat),
+                      dtype=dname)
+    touched = np.bincount(row.numpy(), minlength=n_total) > 0
+    remote = touched.copy()
+    remote[lo:hi] = False
+    assert np.array_equal(ids.cpu().numpy(), np.nonzero(remote)[0])
+    assert np.array_equal(to_np(rows), exp[remote])
+    assert np.array_equal(to_np(own()), exp[lo:hi])
+
+
 def test_accumulate_and_combine(local, oracle):
     n_local, D = 500, 12
     g = torch.Generator().manual_seed(5)
