@@ -153,82 +153,144 @@ __global__ void zero_empty_kernel(T* __restrict__ out, const int64_t* __restrict
 constexpr int LDS_THREADS = 1024;
 constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
 
+// Launch order -> work item: consecutive block ids go round-robin to the 8 XCDs (each with its own L2), so XCD x is given
+// a CONTIGUOUS run of items: neighbouring column strips — which share the 64/128-B lines of every src / index row — are
+// then streamed at the same time through the same L2 instead of being fetched once per XCD.
+__device__ inline int64_t xcd_contiguous(int64_t bid, int64_t total) {
+    const int64_t q = total / 8, r = total % 8, x = bid % 8;
+    return x * q + (x < r ? x : r) + bid / 8;
+}
+
 template <typename T, int R>
 __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __restrict__ src,
                                                                   const int64_t* __restrict__ index,
                                                                   T* __restrict__ out, int64_t* __restrict__ arg_out,
                                                                   int64_t B, int64_t E, int64_t K, int64_t N, int TC,
                                                                   int strips, int64_t rows, int nchunks,
-                                                                  int init_from_out) {
-    // blockIdx.x = (b * strips + strip) * nchunks + chunk; the chunk owns destinations [n_lo, n_lo + nloc)
+                                                                  int init_from_out, int tshift) {
+    // item = (b * strips + strip) * nchunks + chunk; the chunk owns destinations [n_lo, n_lo + nloc)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* acc = reinterpret_cast<float*>(lds_raw);
     int* aux = reinterpret_cast<int*>(lds_raw) + (size_t)rows * TC;  // counts (MEAN) or arg (MIN/MAX)
     constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
-    const int chunk = (int)(blockIdx.x % nchunks);
-    const int64_t bs = blockIdx.x / nchunks;
+    constexpr int UNR = 8;  // loads in flight per thread: the strip is streamed, not chased
+    const int64_t item = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int chunk = (int)(item % nchunks);
+    const int64_t bs = item / nchunks;
     const int64_t b = bs / strips;
     const int64_t k0 = (int64_t)(bs % strips) * TC;
     const int tc = (int)((K - k0 < TC) ? (K - k0) : TC);
     const int64_t n_lo = (int64_t)chunk * rows;
-    const int64_t nloc = (N - n_lo < rows) ? (N - n_lo) : rows;
-    const int64_t nacc = nloc * tc;
+    const int nloc = (int)((N - n_lo < rows) ? (N - n_lo) : rows);
     const float ident = (R == GNNOPS_MUL) ? 1.f : (R == GNNOPS_MIN) ? __builtin_huge_valf()
                         : (R == GNNOPS_MAX) ? -__builtin_huge_valf() : 0.f;
+    // thread -> (row slot er, column kk of the strip): kk = tid mod 2^tshift (2^tshift >= TC), no divisions anywhere
+    const int kk = threadIdx.x & ((1 << tshift) - 1);
+    const int er = threadIdx.x >> tshift;
+    const int rpi = (int)blockDim.x >> tshift;  // rows per sweep of the workgroup
+    const bool col_ok = kk < tc;
 
-    for (int64_t i = threadIdx.x; i < nacc; i += LDS_THREADS) {
-        const int64_t n = n_lo + i / tc, kk = i % tc;
-        acc[i] = init_from_out ? Elem<T>::load(out + (b * N + n) * K + k0 + kk) : ident;
-        if (R == GNNOPS_MEAN) aux[i] = 0;
-        if (IS_ARG) aux[i] = (int)E;
+    if (col_ok) {
+        for (int r0 = er; r0 < nloc; r0 += rpi * UNR) {
+            float iv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {  // unconditional, clamped loads: all in flight together (see below)
+                const int r = r0 + u * rpi;
+                const int rc = r < nloc ? r : nloc - 1;
+                iv[u] = init_from_out ? Elem<T>::load(out + (b * N + n_lo + rc) * K + k0 + kk) : ident;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * rpi;
+                if (r < nloc) {
+                    const int i = r * tc + kk;
+                    acc[i] = iv[u];
+                    if (R == GNNOPS_MEAN) aux[i] = 0;
+                    if (IS_ARG) aux[i] = (int)E;
+                }
+            }
+        }
     }
     __syncthreads();
 
-    const int64_t nsrc = E * tc;
-    for (int64_t i = threadIdx.x; i < nsrc; i += LDS_THREADS) {
-        const int64_t e = i / tc, kk = i % tc;
-        const int64_t s = (b * E + e) * K + k0 + kk;
-        const int64_t nl = index[s] - n_lo;
-        if (nl < 0 || nl >= nloc) continue;  // another chunk's destination
-        const int64_t a = nl * tc + kk;
-        const float v = Elem<T>::load(src + s);
-        if constexpr (R == GNNOPS_SUM) {
-            atomicAdd(&acc[a], v);
-        } else if constexpr (R == GNNOPS_MEAN) {
-            atomicAdd(&acc[a], v);
-            atomicAdd(&aux[a], 1);
-        } else if constexpr (R == GNNOPS_MUL) {
-            atomic_update(&acc[a], v, [](float x, float y) { return x * y; });
-        } else if constexpr (R == GNNOPS_MIN) {
-            atomic_update(&acc[a], v, [](float x, float y) { return y < x ? y : x; });
-        } else {
-            atomic_update(&acc[a], v, [](float x, float y) { return y > x ? y : x; });
+    const T* sp = src + (b * E) * K + k0 + kk;
+    const int64_t* ip = index + (b * E) * K + k0 + kk;
+    if (col_ok) {
+        for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
+            int64_t nl[UNR];
+            float v[UNR];
+            // unconditional loads (rows past the end re-read row E-1 and are masked afterwards): a load under a branch
+            // is waited for inside the branch, which serialises the sixteen of them
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t e = e0 + (int64_t)u * rpi;
+                const int64_t ec = e < E ? e : E - 1;
+                nl[u] = ip[ec * K];
+                v[u] = Elem<T>::load(sp + ec * K);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) nl[u] = (e0 + (int64_t)u * rpi < E) ? nl[u] - n_lo : -1;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (nl[u] < 0 || nl[u] >= nloc) continue;  // past the end, or another chunk's destination
+                const int a = (int)nl[u] * tc + kk;
+                // the float add goes through a read + compare-and-swap on LDS, not ds_add_f32: measured on gfx950, the
+                // float LDS atomic costs ~170 LDS-array cycles per wave-instruction (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS)
+                // and bounded this kernel; the integer CAS path does not
+                if constexpr (R == GNNOPS_SUM) {
+                    atomic_update(&acc[a], v[u], [](float x, float y) { return x + y; });
+                } else if constexpr (R == GNNOPS_MEAN) {
+                    atomic_update(&acc[a], v[u], [](float x, float y) { return x + y; });
+                    atomicAdd(&aux[a], 1);
+                } else if constexpr (R == GNNOPS_MUL) {
+                    atomic_update(&acc[a], v[u], [](float x, float y) { return x * y; });
+                } else if constexpr (R == GNNOPS_MIN) {
+                    atomic_update(&acc[a], v[u], [](float x, float y) { return y < x ? y : x; });
+                } else {
+                    atomic_update(&acc[a], v[u], [](float x, float y) { return y > x ? y : x; });
+                }
+            }
         }
     }
     __syncthreads();
 
     if constexpr (IS_ARG) {  // smallest position attaining the extremum
-        for (int64_t i = threadIdx.x; i < nsrc; i += LDS_THREADS) {
-            const int64_t e = i / tc, kk = i % tc;
-            const int64_t s = (b * E + e) * K + k0 + kk;
-            const int64_t nl = index[s] - n_lo;
-            if (nl < 0 || nl >= nloc) continue;
-            const int64_t a = nl * tc + kk;
-            if (Elem<T>::load(src + s) == acc[a]) atomicMin(&aux[a], (int)e);
+        if (col_ok) {
+            for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
+                int64_t nl[UNR];
+                float v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int64_t e = e0 + (int64_t)u * rpi;
+                    const int64_t ec = e < E ? e : E - 1;
+                    nl[u] = ip[ec * K];
+                    v[u] = Elem<T>::load(sp + ec * K);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) nl[u] = (e0 + (int64_t)u * rpi < E) ? nl[u] - n_lo : -1;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (nl[u] < 0 || nl[u] >= nloc) continue;
+                    const int a = (int)nl[u] * tc + kk;
+                    if (v[u] == acc[a]) atomicMin(&aux[a], (int)(e0 + (int64_t)u * rpi));
+                }
+            }
         }
         __syncthreads();
     }
 
-    for (int64_t i = threadIdx.x; i < nacc; i += LDS_THREADS) {
-        const int64_t n = n_lo + i / tc, kk = i % tc;
-        const int64_t o = (b * N + n) * K + k0 + kk;
-        float v = acc[i];
-        if (R == GNNOPS_MEAN) v = v / (float)(aux[i] < 1 ? 1 : aux[i]);
-        if (IS_ARG) {
-            if (!init_from_out && aux[i] == (int)E) v = 0.f;
-            if (arg_out) arg_out[o] = aux[i];
+    if (col_ok) {
+        for (int r = er; r < nloc; r += rpi) {
+            const int i = r * tc + kk;
+            const int64_t o = (b * N + n_lo + r) * K + k0 + kk;
+            float v = acc[i];
+            if (R == GNNOPS_MEAN) v = v / (float)(aux[i] < 1 ? 1 : aux[i]);
+            if (IS_ARG) {
+                if (!init_from_out && aux[i] == (int)E) v = 0.f;
+                if (arg_out) arg_out[o] = aux[i];
+            }
+            Elem<T>::store(out + o, v);
         }
-        Elem<T>::store(out + o, v);
     }
 }
 
@@ -270,8 +332,13 @@ int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int
     const size_t per = (R == GNNOPS_SUM || R == GNNOPS_MUL) ? 4 : 8;
     const int strips = (int)gnnops_cdiv(K, g.tc);
     const size_t lds = (size_t)g.rows * g.tc * per;
-    hipLaunchKernelGGL((scatter_lds_kernel<T, R>), dim3((unsigned)(B * strips * g.nchunks)), dim3(LDS_THREADS), lds, stream,
-                       src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks, init_from_out);
+    int tshift = 0;
+    while ((1 << tshift) < g.tc) ++tshift;
+    // a strip that leaves room for several workgroups per CU gets smaller ones: more of them resident, their
+    // init / stream / write-back phases overlap (the kernel needs ~70 VGPRs: one 1024-thread workgroup per CU otherwise)
+    const int threads = lds > 80 * 1024 ? LDS_THREADS : lds > 40 * 1024 ? 512 : 256;
+    hipLaunchKernelGGL((scatter_lds_kernel<T, R>), dim3((unsigned)(B * strips * g.nchunks)), dim3(threads), lds, stream,
+                       src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks, init_from_out, tshift);
     return gnnops_check_launch("scatter_lds");
 }
 
