@@ -74,10 +74,113 @@ __global__ __launch_bounds__(256) void fused_rows_kernel(const T* __restrict__ i
     if (lane == 0) out[b] = acc;
 }
 
+// K == 1, rows of `other` that fit in LDS (the reference's (L, L) fp16 shapes): a workgroup parks TB rows other[b, :] on
+// chip with coalesced 16-B loads, then every thread walks destinations n (four at a time, so their row-pointer, input and
+// perm loads are in flight together) and reads the contributions from LDS instead of gathering 2-byte values from HBM.
+constexpr int FR_THREADS = 512, FR_MAX_TB = 4, FR_U = 4;
+constexpr size_t FR_LDS_TARGET = 40 * 1024, FR_LDS_MAX = 64 * 1024;
+
+template <typename T>
+__global__ __launch_bounds__(FR_THREADS) void fused_rows_lds_kernel(const T* __restrict__ input, const T* __restrict__ other,
+                                                                    const int32_t* __restrict__ rowptr,
+                                                                    const int32_t* __restrict__ perm, float* __restrict__ out,
+                                                                    int64_t B, int64_t N, int64_t E, int TB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fr_raw[];
+    T* rows = reinterpret_cast<T*>(fr_raw);  // [TB][E]
+    __shared__ float s_part[FR_THREADS / 64][FR_MAX_TB];
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+    const int tb = (int)((B - b0 < TB) ? (B - b0) : TB);
+    const T* sb = other + b0 * E;
+    const int64_t nelem = (int64_t)tb * E;
+    if ((((uintptr_t)sb) & 15) == 0) {
+        constexpr int PER = 16 / (int)sizeof(T);
+        const int64_t nvec = nelem / PER;
+        const u32x4* sv = reinterpret_cast<const u32x4*>(sb);
+        u32x4* dv = reinterpret_cast<u32x4*>(rows);
+        int64_t i = threadIdx.x;
+        for (; i + 3 * FR_THREADS < nvec; i += 4 * FR_THREADS) {
+            const u32x4 a = sv[i], b = sv[i + FR_THREADS], c = sv[i + 2 * FR_THREADS], d = sv[i + 3 * FR_THREADS];
+            dv[i] = a; dv[i + FR_THREADS] = b; dv[i + 2 * FR_THREADS] = c; dv[i + 3 * FR_THREADS] = d;
+        }
+        for (; i < nvec; i += FR_THREADS) dv[i] = sv[i];
+        for (int64_t j = nvec * PER + threadIdx.x; j < nelem; j += FR_THREADS) rows[j] = sb[j];
+    } else {
+        for (int64_t i = threadIdx.x; i < nelem; i += FR_THREADS) rows[i] = sb[i];
+    }
+    __syncthreads();
+
+    float acc[FR_MAX_TB];
+#pragma unroll
+    for (int t = 0; t < FR_MAX_TB; ++t) acc[t] = 0.f;
+    for (int64_t n0 = threadIdx.x; n0 < N; n0 += (int64_t)FR_THREADS * FR_U) {
+        int32_t beg[FR_U], end[FR_U];
+        float tv[FR_U][FR_MAX_TB];
+#pragma unroll
+        for (int u = 0; u < FR_U; ++u) {
+            const int64_t n = n0 + (int64_t)u * FR_THREADS;
+            const int64_t nc = n < N ? n : N - 1;
+            beg[u] = rowptr[nc];
+            end[u] = rowptr[nc + 1];
+#pragma unroll
+            for (int t = 0; t < FR_MAX_TB; ++t) tv[u][t] = (t < tb) ? Elem<T>::load(input + (b0 + t) * N + nc) : 0.f;
+        }
+        int32_t maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < FR_U; ++u) {
+            if (n0 + (int64_t)u * FR_THREADS >= N) end[u] = beg[u];
+            maxlen = (end[u] - beg[u] > maxlen) ? end[u] - beg[u] : maxlen;
+        }
+        for (int32_t sidx = 0; sidx < maxlen; ++sidx) {
+            int32_t e[FR_U];
+#pragma unroll
+            for (int u = 0; u < FR_U; ++u) {
+                const int32_t j = beg[u] + sidx;
+                e[u] = (j < end[u]) ? perm[j < end[u] ? j : beg[u]] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < FR_U; ++u) {
+                if (e[u] < 0) continue;
+#pragma unroll
+                for (int t = 0; t < FR_MAX_TB; ++t)
+                    if (t < tb) tv[u][t] += Elem<T>::load(rows + (int64_t)t * E + e[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FR_U; ++u) {
+            const int32_t cnt = end[u] - beg[u];
+            if (cnt == 0) continue;  // the row is never selected
+#pragma unroll
+            for (int t = 0; t < FR_MAX_TB; ++t)
+                if (t < tb) acc[t] += (float)cnt * round_to<T>(tv[u][t]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < FR_MAX_TB; ++t) {
+        float a = acc[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) s_part[wave][t] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < tb) {
+        float a = 0.f;
+        for (int w = 0; w < FR_THREADS / 64; ++w) a += s_part[w][threadIdx.x];
+        out[b0 + threadIdx.x] = a;
+    }
+}
+
 template <typename T>
 int launch(const void* input, const void* other, const int32_t* rowptr, const int32_t* perm, float* out, int64_t B,
            int64_t N, int64_t E, int64_t K, float* partial, hipStream_t stream) {
-    if (K == 1) {
+    if (K == 1 && E >= 512 && N >= FR_THREADS / 2 && (size_t)E * sizeof(T) <= FR_LDS_MAX) {
+        int tb = (int)(FR_LDS_TARGET / ((size_t)E * sizeof(T)));
+        if (tb < 1) tb = 1;
+        if (tb > FR_MAX_TB) tb = FR_MAX_TB;
+        if (tb > B) tb = (int)B;
+        hipLaunchKernelGGL((fused_rows_lds_kernel<T>), dim3((unsigned)gnnops_cdiv(B, tb)), dim3(FR_THREADS),
+                           (size_t)tb * E * sizeof(T), stream, (const T*)input, (const T*)other, rowptr, perm, out, B, N, E, tb);
+    } else if (K == 1) {
         const int grid = (int)gnnops_cdiv(B * 64, 256);
         hipLaunchKernelGGL((fused_rows_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)input, (const T*)other,
                            rowptr, perm, out, B, N, E);

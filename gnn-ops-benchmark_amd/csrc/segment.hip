@@ -151,12 +151,141 @@ __global__ __launch_bounds__(256) void seg_elems_kernel(const T* __restrict__ sr
     }
 }
 
+// K == 1 with a batch in front (the reference's index_add_ case: (L, L) matrices, dim = 1, one index for every row —
+// benchmark_native_index_add_.py:13-16,62): out[b, n] = reduce over e in segment n of src[b, e]. The generic element
+// kernel gathers 2-byte values from HBM; here a workgroup parks TB whole rows src[b, :] in LDS with coalesced loads and
+// every thread walks the segment of its destination once for all TB rows, reading the values from LDS. No atomics:
+// contributions are combined in ascending position, as everywhere else.
+constexpr int K1_THREADS = 512;
+constexpr int K1_MAX_TB = 4;
+constexpr int K1_U = 4;  // destinations per thread per sweep
+constexpr size_t K1_LDS_BYTES = 64 * 1024;   // largest row taken
+constexpr size_t K1_LDS_TARGET = 40 * 1024;  // LDS per workgroup aimed at
+
+template <typename T, int R>
+__global__ __launch_bounds__(K1_THREADS) void seg_k1_kernel(const T* __restrict__ src, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ perm, T* __restrict__ out,
+                                                            int64_t* __restrict__ arg_out, int64_t B, int64_t E, int64_t N,
+                                                            int TB, int init_from_out, int is_mean) {
+    constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
+    extern __shared__ __attribute__((aligned(16))) unsigned char k1_raw[];
+    T* rows = reinterpret_cast<T*>(k1_raw);  // [TB][E]
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+    const int tb = (int)((B - b0 < TB) ? (B - b0) : TB);
+    const T* sb = src + b0 * E;
+    const int64_t nelem = (int64_t)tb * E;  // the tb rows are contiguous in src
+    if ((((uintptr_t)sb) & 15) == 0) {
+        constexpr int PER = 16 / (int)sizeof(T);
+        const int64_t nvec = nelem / PER;
+        const u32x4* sv = reinterpret_cast<const u32x4*>(sb);
+        u32x4* dv = reinterpret_cast<u32x4*>(rows);
+        int64_t i = threadIdx.x;
+        for (; i + 3 * K1_THREADS < nvec; i += 4 * K1_THREADS) {  // four 16-B loads in flight per thread
+            const u32x4 a = sv[i], b = sv[i + K1_THREADS], c = sv[i + 2 * K1_THREADS], d = sv[i + 3 * K1_THREADS];
+            dv[i] = a; dv[i + K1_THREADS] = b; dv[i + 2 * K1_THREADS] = c; dv[i + 3 * K1_THREADS] = d;
+        }
+        for (; i < nvec; i += K1_THREADS) dv[i] = sv[i];
+        for (int64_t j = nvec * PER + threadIdx.x; j < nelem; j += K1_THREADS) rows[j] = sb[j];
+    } else {
+        for (int64_t i = threadIdx.x; i < nelem; i += K1_THREADS) rows[i] = sb[i];
+    }
+    __syncthreads();
+
+    // K1_U destinations per thread at a time, so that the row-pointer, out and perm loads of all of them are in flight
+    // together (loads are unconditional on clamped indices: a load under a branch is waited for inside the branch)
+    for (int64_t n0 = threadIdx.x; n0 < N; n0 += (int64_t)K1_THREADS * K1_U) {
+        int32_t beg[K1_U], end[K1_U];
+        int64_t nn[K1_U];
+#pragma unroll
+        for (int u = 0; u < K1_U; ++u) {
+            const int64_t n = n0 + (int64_t)u * K1_THREADS;
+            nn[u] = n < N ? n : N - 1;
+            beg[u] = rowptr[nn[u]];
+            end[u] = rowptr[nn[u] + 1];
+        }
+        float acc[K1_U][K1_MAX_TB];
+        int32_t arg[K1_U][K1_MAX_TB];
+#pragma unroll
+        for (int u = 0; u < K1_U; ++u)
+#pragma unroll
+            for (int t = 0; t < K1_MAX_TB; ++t) {
+                arg[u][t] = (int32_t)E;
+                acc[u][t] = Red<R>::identity();
+                if (init_from_out && t < tb) acc[u][t] = Elem<T>::load(out + (b0 + t) * N + nn[u]);
+            }
+        int32_t maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < K1_U; ++u) {
+            if (n0 + (int64_t)u * K1_THREADS >= N) end[u] = beg[u];  // past the end: nothing to do, nothing stored
+            maxlen = (end[u] - beg[u] > maxlen) ? end[u] - beg[u] : maxlen;
+        }
+        for (int32_t sidx = 0; sidx < maxlen; ++sidx) {
+            int32_t e[K1_U];
+#pragma unroll
+            for (int u = 0; u < K1_U; ++u) {
+                const int32_t j = beg[u] + sidx;
+                const int32_t jc = j < end[u] ? j : beg[u];   // beg[u] < E whenever the segment is not empty
+                e[u] = (j < end[u]) ? (perm ? perm[jc] : jc) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < K1_U; ++u) {
+                if (e[u] < 0) continue;
+#pragma unroll
+                for (int t = 0; t < K1_MAX_TB; ++t) {
+                    if (t < tb) {
+                        const float f = Elem<T>::load(rows + (int64_t)t * E + e[u]);
+                        if constexpr (IS_ARG) {
+                            if (Red<R>::better(f, acc[u][t])) { acc[u][t] = f; arg[u][t] = e[u]; }
+                        } else {
+                            acc[u][t] = Red<R>::apply(acc[u][t], f);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < K1_U; ++u) {
+            const int64_t n = n0 + (int64_t)u * K1_THREADS;
+            if (n >= N) continue;
+            const int32_t len = end[u] - beg[u];
+            if (len == 0 && init_from_out && !(IS_ARG && arg_out)) continue;  // the out row stays as it is
+#pragma unroll
+            for (int t = 0; t < K1_MAX_TB; ++t) {
+                if (t < tb) {
+                    float v = acc[u][t];
+                    const int64_t o = (b0 + t) * N + n;
+                    if constexpr (IS_ARG) {
+                        if (!init_from_out && arg[u][t] == (int32_t)E) v = 0.f;
+                        if (arg_out) arg_out[o] = arg[u][t];
+                    } else if (R == GNNOPS_SUM) {
+                        if (is_mean) v = v / (float)(len < 1 ? 1 : len);
+                    }
+                    Elem<T>::store(out + o, v);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int R>
 int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void* out, int64_t* arg_out, int64_t B,
                int64_t E, int64_t K, int64_t N, int init_from_out, int is_mean, hipStream_t stream) {
     constexpr int VEC = Elem<T>::VEC;
     const bool aligned = ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
                          (arg_out == nullptr || (uintptr_t)arg_out % 16 == 0);
+    // (small N or E: too little work per workgroup — the element kernel's thread-per-output mapping is the better one)
+    if (K == 1 && B > 1 && E >= 512 && N >= K1_THREADS / 2 && (size_t)E * sizeof(T) <= K1_LDS_BYTES) {
+        // rows per workgroup: as many as fit 40 KiB, so that four 512-thread workgroups share a CU (measured at the
+        // reference's (10000, 10000) fp16 index_add_: 0.28 ms with two rows / 40 KB, 0.40 ms with one or with three)
+        int tb = (int)(K1_LDS_TARGET / ((size_t)E * sizeof(T)));
+        if (tb < 1) tb = 1;
+        if (tb > K1_MAX_TB) tb = K1_MAX_TB;
+        if (tb > B) tb = (int)B;
+        hipLaunchKernelGGL((seg_k1_kernel<T, R>), dim3((unsigned)gnnops_cdiv(B, tb)), dim3(K1_THREADS),
+                           (size_t)tb * E * sizeof(T), stream, (const T*)src, rowptr, perm, (T*)out, arg_out, B, E, N, tb,
+                           init_from_out, is_mean);
+        return gnnops_check_launch("segment_reduce");
+    }
     if (K % VEC == 0 && aligned) {
         const int64_t vecs = K / VEC;  // 16-B lanes per row
         int gshift = 0;

@@ -327,3 +327,30 @@ def test_config1_scatter_add(gnnops, oracle):
     got = gnnops.scatter_add(src.cuda(), idx.cuda(), dim=0)
     exp = oracle.scatter(src.numpy(), idx.numpy(), 0)
     assert_bits_equal(got.cpu().numpy(), exp, "config 1")
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max", "mul"])
+@pytest.mark.parametrize("B,E,N", [(37, 1001, 300), (5, 4096, 4096), (300, 600, 256)])
+def test_batched_k1_rows_in_lds(gnnops, oracle, B, E, N, reduce, dname):
+    """src [B, E] reduced along dim 1 with ONE row index for every b (layout R, K == 1): the LDS-staged kernel of
+    segment.hip (whole rows parked on chip, no atomics) — bit-exact against the sequential oracle, ragged last tile of
+    rows, row lengths that are not 16-B multiples, empty destinations, and accumulation into `out`."""
+    g = torch.Generator().manual_seed(B + E)
+    src = (torch.rand(B, E, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    if reduce == "mul":
+        src = (1 + src.float() / 8).to(TORCH_DT[dname])
+    idx = torch.randint(0, N, (E,), generator=g)
+    idx[idx % 11 == 3] = 0
+    got = gnnops.scatter(src.cuda(), idx.cuda(), 1, dim_size=N, reduce=reduce)
+    exp = oracle.scatter(to_np(src), idx.numpy(), dim=1, dim_size=N, reduce=reduce, dtype=dname)
+    if reduce in ("min", "max"):
+        assert_bits_equal(to_np(got[0]), exp[0], "values")
+        assert np.array_equal(got[1].cpu().numpy(), exp[1])
+    else:
+        assert_bits_equal(to_np(got), exp, reduce)
+    if reduce == "sum":
+        base = (torch.rand(B, N, generator=g)).to(TORCH_DT[dname])
+        out = base.clone().cuda()
+        gnnops.index_add_(out, 1, idx.cuda(), src.cuda())
+        assert_bits_equal(to_np(out), oracle.index_add_(to_np(base), 1, idx.numpy(), to_np(src), dtype=dname), "index_add_")
