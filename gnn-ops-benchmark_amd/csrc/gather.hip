@@ -111,27 +111,77 @@ __global__ __launch_bounds__(256) void select_elems_kernel(const U* __restrict__
 constexpr int GL_THREADS = 1024;
 constexpr size_t GL_BUDGET = 160 * 1024 - 512;
 
+// Consecutive block ids go round-robin to the 8 XCDs; give each XCD a contiguous run of work items so that neighbouring
+// column strips (which share the 64/128-B lines of every input / index row) stream through the same L2.
+__device__ inline int64_t gl_xcd_contiguous(int64_t bid, int64_t total) {
+    const int64_t q = total / 8, r = total % 8, x = bid % 8;
+    return x * q + (x < r ? x : r) + bid / 8;
+}
+
 template <typename U, bool FULL_INDEX>
 __global__ __launch_bounds__(GL_THREADS) void gather_lds_kernel(const U* __restrict__ in, const int64_t* __restrict__ index,
                                                                 U* __restrict__ out, int64_t B, int64_t N, int64_t K,
-                                                                int64_t E, int TC, int strips) {
+                                                                int64_t E, int TC, int strips, int tshift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gl_raw[];
     U* tile = reinterpret_cast<U*>(gl_raw);
-    const int64_t b = blockIdx.x / strips;
-    const int64_t k0 = (int64_t)(blockIdx.x % strips) * TC;
+    constexpr int UNR = 8;  // loads in flight per thread (unconditional, on clamped rows: a load under a branch is
+                            // waited for inside the branch)
+    const int64_t item = gl_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int64_t b = item / strips;
+    const int64_t k0 = (int64_t)(item % strips) * TC;
     const int tc = (int)((K - k0 < TC) ? (K - k0) : TC);
-    const int64_t nin = N * tc;
-    for (int64_t i = threadIdx.x; i < nin; i += GL_THREADS) {
-        const int64_t n = i / tc, kk = i % tc;
-        tile[i] = in[(b * N + n) * K + k0 + kk];
+    const int threads = (int)blockDim.x;
+    // thread -> (row slot er, column kk of the strip), kk = tid mod 2^tshift >= TC: no divisions
+    const int kk = threadIdx.x & ((1 << tshift) - 1);
+    const int er = threadIdx.x >> tshift;
+    const int rpi = threads >> tshift;
+    const bool col_ok = kk < tc;
+
+    const U* ib = in + (b * N) * K + k0;
+    if (K == 1 && (((uintptr_t)ib) & 15) == 0) {  // the strip is the whole contiguous row: 16-B loads
+        constexpr int PER = 16 / (int)sizeof(U);
+        const int64_t nvec = N / PER;
+        const u32x4* sv = reinterpret_cast<const u32x4*>(ib);
+        u32x4* dv = reinterpret_cast<u32x4*>(tile);
+        int64_t i = threadIdx.x;
+        for (; i + 3 * threads < nvec; i += 4 * threads) {
+            const u32x4 a = sv[i], c = sv[i + threads], d = sv[i + 2 * threads], f = sv[i + 3 * threads];
+            dv[i] = a; dv[i + threads] = c; dv[i + 2 * threads] = d; dv[i + 3 * threads] = f;
+        }
+        for (; i < nvec; i += threads) dv[i] = sv[i];
+        for (int64_t j = nvec * PER + threadIdx.x; j < N; j += threads) tile[j] = ib[j];
+    } else if (col_ok) {
+        for (int64_t n0 = er; n0 < N; n0 += (int64_t)rpi * UNR) {
+            U v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t n = n0 + (int64_t)u * rpi;
+                v[u] = ib[(n < N ? n : N - 1) * K + kk];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t n = n0 + (int64_t)u * rpi;
+                if (n < N) tile[n * tc + kk] = v[u];
+            }
+        }
     }
     __syncthreads();
-    const int64_t nout = E * tc;
-    for (int64_t i = threadIdx.x; i < nout; i += GL_THREADS) {
-        const int64_t e = i / tc, kk = i % tc;
-        const int64_t o = (b * E + e) * K + k0 + kk;
-        const int64_t n = FULL_INDEX ? index[o] : index[e];
-        out[o] = tile[n * tc + kk];
+    if (!col_ok) return;
+    U* ob = out + (b * E) * K + k0 + kk;
+    const int64_t* xb = FULL_INDEX ? index + (b * E) * K + k0 + kk : index;
+    const int64_t xstride = FULL_INDEX ? K : 1;
+    for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
+        int64_t n[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t e = e0 + (int64_t)u * rpi;
+            n[u] = xb[(e < E ? e : E - 1) * xstride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t e = e0 + (int64_t)u * rpi;
+            if (e < E) ob[e * K] = tile[n[u] * tc + kk];
+        }
     }
 }
 
@@ -157,8 +207,13 @@ int launch_gather_lds(const void* in, const int64_t* index, void* out, int64_t B
         configured = true;
     }
     const int strips = (int)gnnops_cdiv(K, tc);
-    hipLaunchKernelGGL((gather_lds_kernel<U, FULL_INDEX>), dim3((unsigned)(B * strips)), dim3(GL_THREADS),
-                       (size_t)N * tc * sizeof(U), stream, (const U*)in, index, (U*)out, B, N, K, E, tc, strips);
+    int tshift = 0;
+    while ((1 << tshift) < tc) ++tshift;
+    const size_t lds = (size_t)N * tc * sizeof(U);
+    // smaller workgroups when several fit a CU: their stage / gather phases overlap
+    const int threads = lds > 80 * 1024 ? GL_THREADS : lds > 40 * 1024 ? 512 : 256;
+    hipLaunchKernelGGL((gather_lds_kernel<U, FULL_INDEX>), dim3((unsigned)(B * strips)), dim3(threads), lds, stream,
+                       (const U*)in, index, (U*)out, B, N, K, E, tc, strips, tshift);
     return gnnops_check_launch("gather_lds");
 }
 
