@@ -5,6 +5,7 @@
 // All HBM-bound byte movers: 16-B lane accesses along the feature dimension, several rows in flight
 // per lane group to cover the dependent index -> row latency. No MFMA here by design.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -337,6 +338,84 @@ inline RowGeom row_geom(int64_t vecs) {
     return g;
 }
 
+// Long rows whose byte length is not a multiple of 16 (the reference's (L, L) fp16 sweeps: 2 L bytes, e.g. 28284): source
+// and destination rows are then misaligned relative to each other, so the copy unit is the widest type that divides the
+// row (4 or 8 bytes, 2 for odd L). One wave per output row: the index is read once per row, the lanes sweep the row with
+// eight loads in flight each, no per-element division (the element kernel pays one per element).
+template <typename U>
+__global__ __launch_bounds__(256) void select_longrows_kernel(const U* __restrict__ in, const int64_t* __restrict__ index,
+                                                              U* __restrict__ out, int64_t B, int64_t N, int64_t KU,
+                                                              int64_t E) {
+    constexpr int UNR = 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t item = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < B * E; item += nwaves) {
+        const int64_t b = item / E, e = item - b * E;
+        const U* src = in + (b * N + index[e]) * KU;
+        U* dst = out + item * KU;
+        for (int64_t k0 = lane; k0 < KU; k0 += 64 * UNR) {
+            U v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t k = k0 + 64 * u;
+                v[u] = __builtin_nontemporal_load(src + (k < KU ? k : KU - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t k = k0 + 64 * u;
+                if (k < KU) __builtin_nontemporal_store(v[u], dst + k);
+            }
+        }
+    }
+}
+
+// fused index_select + sum over such rows: the same sweep, PAIR = 2 sums two 16-bit values per 4-byte load.
+template <typename T, int PAIR>
+__global__ __launch_bounds__(256) void select_sum_longrows_kernel(const T* __restrict__ in, const int64_t* __restrict__ index,
+                                                                  float* __restrict__ partial, int64_t B, int64_t N,
+                                                                  int64_t K, int64_t E) {
+    constexpr int UNR = 8;
+    // raw bits: a 4-byte pair of 16-bit values, or one value as an unsigned integer of its own width
+    using Raw = typename std::conditional<sizeof(T) == 4, uint32_t, uint16_t>::type;
+    using Unit = typename std::conditional<PAIR == 2, uint32_t, Raw>::type;
+    __shared__ float s_part[4];
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t KU = K / PAIR;
+    float acc = 0.f;
+    for (int64_t item = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < B * E; item += nwaves) {
+        const int64_t b = item / E, e = item - b * E;
+        const Unit* src = reinterpret_cast<const Unit*>(in + (b * N + index[e]) * K);
+        for (int64_t k0 = lane; k0 < KU; k0 += 64 * UNR) {
+            Unit v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t k = k0 + 64 * u;
+                v[u] = __builtin_nontemporal_load(src + (k < KU ? k : KU - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (k0 + 64 * u < KU) {
+                    if constexpr (PAIR == 2) {
+                        const uint16_t lo = (uint16_t)(v[u] & 0xffffu), hi = (uint16_t)(v[u] >> 16);
+                        acc += Elem<T>::load(reinterpret_cast<const T*>(&lo));
+                        acc += Elem<T>::load(reinterpret_cast<const T*>(&hi));
+                    } else {
+                        acc += Elem<T>::load(reinterpret_cast<const T*>(&v[u]));
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+constexpr int64_t LONGROW_MIN_UNITS = 512;  // from here on a wave per row beats a thread per element
+
 template <typename T>
 int launch_select_sum(const void* input, const int64_t* index, float* d_sum, int64_t B, int64_t N, int64_t K,
                       int64_t E, float* partial, hipStream_t stream) {
@@ -360,6 +439,14 @@ int launch_select_sum(const void* input, const int64_t* index, float* d_sum, int
         grid = gnnops_grid_cap(B, FUSED_BLOCKS);
         hipLaunchKernelGGL((select_sum_lds_kernel<T>), dim3(grid), dim3(1024), (size_t)N * sizeof(T), stream, (const T*)input,
                            index, partial, B, N, E);
+    } else if (K >= LONGROW_MIN_UNITS) {
+        grid = gnnops_grid_cap(gnnops_cdiv(B * E, 4), FUSED_BLOCKS);
+        if (sizeof(T) == 2 && K % 2 == 0 && (uintptr_t)input % 4 == 0)
+            hipLaunchKernelGGL((select_sum_longrows_kernel<T, 2>), dim3(grid), dim3(256), 0, stream, (const T*)input, index,
+                               partial, B, N, K, E);
+        else
+            hipLaunchKernelGGL((select_sum_longrows_kernel<T, 1>), dim3(grid), dim3(256), 0, stream, (const T*)input, index,
+                               partial, B, N, K, E);
     } else {
         grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256 * 4), FUSED_BLOCKS);
         hipLaunchKernelGGL((select_sum_elems_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)input, index,
@@ -401,6 +488,24 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
         }
         // copy in the widest unit that divides the row and the base alignment (a row is one opaque byte string)
         const uintptr_t al = (uintptr_t)input | (uintptr_t)out | (uintptr_t)rowbytes;
+        const int unit = al % 8 == 0 ? 8 : al % 4 == 0 ? 4 : al % 2 == 0 ? 2 : 1;
+        if (rowbytes / unit >= LONGROW_MIN_UNITS) {
+            const int lgrid = gnnops_grid_cap(gnnops_cdiv(B * E, 4), 256 * 32);
+            const int64_t KU = rowbytes / unit;
+            if (unit == 8)
+                hipLaunchKernelGGL((select_longrows_kernel<uint64_t>), dim3(lgrid), dim3(256), 0, stream, (const uint64_t*)input,
+                                   index, (uint64_t*)out, B, N, KU, E);
+            else if (unit == 4)
+                hipLaunchKernelGGL((select_longrows_kernel<uint32_t>), dim3(lgrid), dim3(256), 0, stream, (const uint32_t*)input,
+                                   index, (uint32_t*)out, B, N, KU, E);
+            else if (unit == 2)
+                hipLaunchKernelGGL((select_longrows_kernel<uint16_t>), dim3(lgrid), dim3(256), 0, stream, (const uint16_t*)input,
+                                   index, (uint16_t*)out, B, N, KU, E);
+            else
+                hipLaunchKernelGGL((select_longrows_kernel<uint8_t>), dim3(lgrid), dim3(256), 0, stream, (const uint8_t*)input,
+                                   index, (uint8_t*)out, B, N, KU, E);
+            return gnnops_check_launch("index_select");
+        }
         int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
         if (al % 8 == 0)
             hipLaunchKernelGGL((select_elems_kernel<uint64_t, false>), dim3(grid), dim3(256), 0, stream,

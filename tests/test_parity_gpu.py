@@ -354,3 +354,21 @@ def test_batched_k1_rows_in_lds(gnnops, oracle, B, E, N, reduce, dname):
         out = base.clone().cuda()
         gnnops.index_add_(out, 1, idx.cuda(), src.cuda())
         assert_bits_equal(to_np(out), oracle.index_add_(to_np(base), 1, idx.numpy(), to_np(src), dtype=dname), "index_add_")
+
+
+@pytest.mark.parametrize("dt,K", [(torch.float16, 1001), (torch.float16, 1002), (torch.float16, 1004), (torch.float32, 513),
+                                  (torch.float32, 514), (torch.int64, 600), (torch.uint8, 777)])
+def test_index_select_long_misaligned_rows(gnnops, dt, K):
+    """Rows whose byte length is not a multiple of 16 (the reference's (L, L) fp16 shapes): the wave-per-row kernel, in
+    every copy unit (1, 2, 4, 8 bytes), with repeated and unselected rows; bit-exact against torch's own gather."""
+    g = torch.Generator().manual_seed(K)
+    N, E = 300, 700
+    table = (torch.rand(N, K, generator=g) * 200).to(dt).cuda()
+    idx = torch.randint(0, N, (E,), generator=g).cuda()
+    assert torch.equal(gnnops.index_select(table, 0, idx), table[idx])
+    t3 = (torch.rand(3, N, K, generator=g) * 200).to(dt).cuda()      # a batch in front
+    assert torch.equal(gnnops.index_select(t3, 1, idx), t3[:, idx])
+    if dt.is_floating_point:
+        got = gnnops.index_select_sum(table, 0, idx).item()
+        exp = table[idx].double().sum().item()
+        assert abs(got - exp) <= 1e-5 * abs(exp) + 1e-3, (got, exp)
