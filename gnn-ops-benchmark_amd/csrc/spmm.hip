@@ -89,6 +89,53 @@ __global__ __launch_bounds__(256) void spmm_elems_kernel(const int32_t* __restri
     }
 }
 
+// Wide dense operands whose rows are not 16-B multiples (the reference's (L, L) fp32 shapes, L = 7071): a workgroup takes
+// (output row i, a run of 256 * UC columns); the row's column ids and values are the same for every lane (scalar loads),
+// each lane keeps UC accumulators and sweeps the nonzeros two at a time, so 2 * UC coalesced element loads are in flight.
+// Same arithmetic and order as the row kernel; no per-element division (spmm_elems_kernel pays one per output element).
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_widerows_kernel(const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ perm,
+                                                            const int64_t* __restrict__ col, const T* __restrict__ value,
+                                                            const T* __restrict__ mat, T* __restrict__ out, int64_t M,
+                                                            int64_t D, int chunks) {
+    constexpr int UC = 4;
+    const int64_t items = M * chunks;
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int64_t i = item / chunks;
+        const int64_t c0 = (item - i * chunks) * (256 * UC) + threadIdx.x;
+        const int32_t beg = rowptr[i], end = rowptr[i + 1];
+        float acc[UC];
+#pragma unroll
+        for (int u = 0; u < UC; ++u) acc[u] = 0.f;
+        for (int32_t j = beg; j < end; j += 2) {
+            const bool two = j + 1 < end;
+            const int32_t e0 = perm ? perm[j] : j, e1 = two ? (perm ? perm[j + 1] : j + 1) : e0;
+            const int64_t r0 = col[e0], r1 = col[e1];
+            const float w0 = value ? Elem<T>::load(value + e0) : 1.f;
+            const float w1 = two ? (value ? Elem<T>::load(value + e1) : 1.f) : 0.f;
+            float x0[UC], x1[UC];
+#pragma unroll
+            for (int u = 0; u < UC; ++u) {
+                const int64_t k = c0 + 256 * u;
+                const int64_t kc = k < D ? k : D - 1;
+                x0[u] = Elem<T>::load(mat + r0 * D + kc);
+                x1[u] = Elem<T>::load(mat + r1 * D + kc);
+            }
+#pragma unroll
+            for (int u = 0; u < UC; ++u) {
+                acc[u] = __fadd_rn(acc[u], __fmul_rn(w0, x0[u]));
+                if (two) acc[u] = __fadd_rn(acc[u], __fmul_rn(w1, x1[u]));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+            const int64_t k = c0 + 256 * u;
+            if (k < D) Elem<T>::store(out + i * D + k, acc[u]);
+        }
+    }
+}
+
 // CSR materialisation of a plan-ordered COO operand: out[j] = in[perm[j]] for the column ids (8 B) or the values.
 template <typename U>
 __global__ void permute_kernel(const U* __restrict__ in, const int32_t* __restrict__ perm, U* __restrict__ out, int64_t n) {
@@ -115,6 +162,11 @@ int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const
         else
             hipLaunchKernelGGL((spmm_rows_kernel<T, false>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col,
                                (const T*)value, (const T*)mat, (T*)out, M, D, gshift, kchunks);
+    } else if (D >= 256) {
+        const int chunks = (int)gnnops_cdiv(D, 256 * 4);
+        const int grid = gnnops_grid_cap(M * chunks, 256 * 32);
+        hipLaunchKernelGGL((spmm_widerows_kernel<T>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col, (const T*)value,
+                           (const T*)mat, (T*)out, M, D, chunks);
     } else {
         const int grid = gnnops_grid_cap(gnnops_cdiv(M * D, 256), 256 * 32);
         hipLaunchKernelGGL((spmm_elems_kernel<T>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col, (const T*)value,

@@ -78,7 +78,7 @@ def test_sort_special_values(gnnops, oracle):
 
 @pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("m,n,D,nnz", [(1000, 800, 64, 20000), (300, 300, 256, 6000), (50, 70, 7, 900), (2000, 2000, 1, 30000),
-                                       (64, 64, 320, 500)])
+                                       (64, 64, 320, 500), (40, 50, 257, 700), (30, 40, 1030, 500), (9, 9, 2049, 30)])
 def test_spmm_bit_exact(gnnops, oracle, m, n, D, nnz, dname):
     g = torch.Generator().manual_seed(5)
     idx = torch.stack([torch.randint(0, m, (nnz,), generator=g), torch.randint(0, n, (nnz,), generator=g)])
