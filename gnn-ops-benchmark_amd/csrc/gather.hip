@@ -193,7 +193,9 @@ inline int gather_lds_width(int64_t N, int64_t K, int64_t E, int elem_bytes) {
     if (tc > 64) tc = 64;
     if (tc >= 8) tc &= ~(int64_t)7;
     if (tc * elem_bytes < 8 && K * elem_bytes >= 8) return 0;  // strips under 8 bytes waste most of every line
-    if (E * 4 < N) return 0;                                    // staging the whole input would cost more than it saves
+    // staging reads the whole strip (N * elem bytes per column); gathering from HBM costs a 32-B sector per selected
+    // element: stage unless fewer than one element per sector-equivalent of the strip is selected
+    if (E * 32 < N * elem_bytes) return 0;
     return (int)tc;
 }
 
@@ -428,7 +430,7 @@ int launch_select_sum(const void* input, const int64_t* index, float* d_sum, int
         grid = gnnops_grid_cap(gnnops_cdiv(items, (256 >> g.gshift) * ROWS_IN_FLIGHT), FUSED_BLOCKS);
         hipLaunchKernelGGL((select_sum_rows_kernel<T, ROWS_IN_FLIGHT>), dim3(grid), dim3(256), 0, stream, (const T*)input,
                            index, partial, B, N, K, E, g.gshift, g.chunks);
-    } else if (K == 1 && (size_t)N * sizeof(T) <= GL_BUDGET && E * 4 >= N) {
+    } else if (K == 1 && (size_t)N * sizeof(T) <= GL_BUDGET && E * 32 >= N * (int64_t)sizeof(T)) {
         static bool configured = false;
         if (!configured) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_sum_lds_kernel<T>),

@@ -294,6 +294,133 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
     }
 }
 
+// min / max in ONE pass over the strip: the LDS cell of a destination is a 64-bit word (order-preserving image of the value
+// << 32 | position), combined with one 64-bit LDS integer atomic per element — smallest value then smallest position for
+// min; for max the low half holds ~position, so the largest word is the largest value at the smallest position. That is
+// the extremum AND its arg in one sweep (the two-pass form above streams src / index twice and spins on a float CAS).
+// -0.0 and +0.0 get the same image (they compare equal: the earlier position wins, like the sequential loop), NaNs never
+// win; the stored value is re-read from src at the winning position, so its bits are exact.
+__device__ inline uint32_t f32_order(float v) {
+    uint32_t u = __float_as_uint(v);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T* __restrict__ src,
+                                                                         const int64_t* __restrict__ index,
+                                                                         T* __restrict__ out, int64_t* __restrict__ arg_out,
+                                                                         int64_t B, int64_t E, int64_t K, int64_t N, int TC,
+                                                                         int strips, int64_t rows, int nchunks,
+                                                                         int init_from_out, int tshift) {
+    static_assert(R == GNNOPS_MIN || R == GNNOPS_MAX, "min / max only");
+    constexpr bool IS_MIN = R == GNNOPS_MIN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* cell = reinterpret_cast<unsigned long long*>(lds_raw);
+    constexpr int UNR = 8;
+    const int64_t item = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int chunk = (int)(item % nchunks);
+    const int64_t bs = item / nchunks;
+    const int64_t b = bs / strips;
+    const int64_t k0 = (int64_t)(bs % strips) * TC;
+    const int tc = (int)((K - k0 < TC) ? (K - k0) : TC);
+    const int64_t n_lo = (int64_t)chunk * rows;
+    const int nloc = (int)((N - n_lo < rows) ? (N - n_lo) : rows);
+    const int kk = threadIdx.x & ((1 << tshift) - 1);
+    const int er = threadIdx.x >> tshift;
+    const int rpi = (int)blockDim.x >> tshift;
+    const bool col_ok = kk < tc;
+    const unsigned long long EMPTY = IS_MIN ? ~0ull : 0ull;
+    // low half: position + 1 (min) or its complement (max); 0 / ~0 stand for "the value already in out", which therefore
+    // wins a tie against any source element — the sequential loop only replaces on a strict improvement
+    const uint32_t lo_out = IS_MIN ? 0u : ~0u;
+    auto winner = [&](unsigned long long c) -> int64_t {  // source position that won the cell, -1 if none did
+        if (c == EMPTY && !init_from_out) return -1;
+        const uint32_t l = IS_MIN ? (uint32_t)c : ~(uint32_t)c;
+        return l == 0u ? -1 : (int64_t)l - 1;
+    };
+
+    if (col_ok) {
+        for (int r0 = er; r0 < nloc; r0 += rpi * UNR) {
+            float iv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * rpi;
+                const int rc = r < nloc ? r : nloc - 1;
+                iv[u] = init_from_out ? Elem<T>::load(out + (b * N + n_lo + rc) * K + k0 + kk) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * rpi;
+                if (r < nloc) {
+                    unsigned long long c = EMPTY;
+                    if (init_from_out)  // a NaN in out is never replaced (nothing compares below / above it)
+                        c = (iv[u] != iv[u]) ? (IS_MIN ? 0ull : ~0ull)
+                                             : (((unsigned long long)f32_order(iv[u]) << 32) | lo_out);
+                    cell[r * tc + kk] = c;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const T* sp = src + (b * E) * K + k0 + kk;
+    const int64_t* ip = index + (b * E) * K + k0 + kk;
+    if (col_ok) {
+        for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
+            int64_t nl[UNR];
+            float v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t e = e0 + (int64_t)u * rpi;
+                const int64_t ec = e < E ? e : E - 1;
+                nl[u] = ip[ec * K];
+                v[u] = Elem<T>::load(sp + ec * K);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t e = e0 + (int64_t)u * rpi;
+                const int64_t d = nl[u] - n_lo;
+                if (e >= E || d < 0 || d >= nloc || v[u] != v[u]) continue;
+                const uint32_t lo = IS_MIN ? (uint32_t)e + 1u : ~((uint32_t)e + 1u);
+                const unsigned long long w = ((unsigned long long)f32_order(v[u]) << 32) | lo;
+                if (IS_MIN) atomicMin(&cell[(int)d * tc + kk], w); else atomicMax(&cell[(int)d * tc + kk], w);
+            }
+        }
+    }
+    __syncthreads();
+
+    if (col_ok) {
+        for (int r0 = er; r0 < nloc; r0 += rpi * UNR) {
+            unsigned long long c[UNR];
+            float val[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * rpi;
+                c[u] = cell[(r < nloc ? r : nloc - 1) * tc + kk];
+                val[u] = 0.f;
+            }
+            if (E > 0) {  // uniform: the eight loads below stay together
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int64_t e = winner(c[u]);
+                    val[u] = Elem<T>::load(sp + (e >= 0 ? e : 0) * K);  // unconditional; ignored when no position won
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * rpi;
+                if (r >= nloc) continue;
+                const int64_t o = (b * N + n_lo + r) * K + k0 + kk;
+                const int64_t e = winner(c[u]);
+                if (arg_out) arg_out[o] = e >= 0 ? e : E;
+                if (e >= 0) Elem<T>::store(out + o, val[u]);
+                else if (!init_from_out) Elem<T>::store(out + o, 0.f);  // torch_scatter: groups nothing reached become 0
+            }
+        }
+    }
+}
+
 // Geometry of the LDS form: strip width TC, destination rows per chunk, chunk count. tc == 0: does not apply.
 // When all N destinations of a strip fit, there is one chunk. Otherwise the destinations are cut into chunks of
 // `rows` and every chunk re-scans the strip's elements, keeping only its own (the (38000, 38000) shapes of
@@ -337,6 +464,18 @@ int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int
     // a strip that leaves room for several workgroups per CU gets smaller ones: more of them resident, their
     // init / stream / write-back phases overlap (the kernel needs ~70 VGPRs: one 1024-thread workgroup per CU otherwise)
     const int threads = lds > 80 * 1024 ? LDS_THREADS : lds > 40 * 1024 ? 512 : 256;
+    if constexpr (R == GNNOPS_MIN || R == GNNOPS_MAX) {
+        static bool configured_mm = false;
+        if (!configured_mm) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_minmax_kernel<T, R>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
+                return gnnops_check_launch("scatter_lds attribute");
+            configured_mm = true;
+        }
+        hipLaunchKernelGGL((scatter_lds_minmax_kernel<T, R>), dim3((unsigned)(B * strips * g.nchunks)), dim3(threads), lds,
+                           stream, src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks, init_from_out, tshift);
+        return gnnops_check_launch("scatter_lds");
+    }
     hipLaunchKernelGGL((scatter_lds_kernel<T, R>), dim3((unsigned)(B * strips * g.nchunks)), dim3(threads), lds, stream,
                        src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks, init_from_out, tshift);
     return gnnops_check_launch("scatter_lds");

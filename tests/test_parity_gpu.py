@@ -372,3 +372,29 @@ def test_index_select_long_misaligned_rows(gnnops, dt, K):
         got = gnnops.index_select_sum(table, 0, idx).item()
         exp = table[idx].double().sum().item()
         assert abs(got - exp) <= 1e-5 * abs(exp) + 1e-3, (got, exp)
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16"])
+@pytest.mark.parametrize("reduce", ["min", "max"])
+def test_layout_f_minmax_ties_zeros_nans(gnnops, oracle, reduce, dname):
+    """Full-shape index (layout F) min / max through the one-pass packed LDS form: massive ties, +0.0 / -0.0 (equal: the
+    earlier position wins and ITS bits are returned), NaNs (never win), empty groups (0, arg = E), accumulation into out."""
+    g = torch.Generator().manual_seed(77)
+    L, N = 300, 40
+    src = torch.randint(-3, 4, (L, L), generator=g).float()      # few distinct values: ties everywhere
+    src[src == 0] = torch.where(torch.rand(int((src == 0).sum()), generator=g) < 0.5, 0.0, -0.0)
+    src[torch.rand(L, L, generator=g) < 0.02] = float("nan")
+    src = src.to(TORCH_DT[dname])
+    idx = torch.randint(0, N, (L, L), generator=g)
+    idx[idx == 7] = 8                                             # group 7 is empty
+    for dim in (0, 1):
+        got, arg = gnnops.scatter(src.cuda(), idx.cuda(), dim, dim_size=N, reduce=reduce)
+        exp, earg = oracle.scatter(to_np(src), idx.numpy(), dim=dim, dim_size=N, reduce=reduce, dtype=dname)
+        assert_bits_equal(to_np(got), exp, f"{reduce} dim {dim}")
+        assert np.array_equal(arg.cpu().numpy(), earg)
+    shape = (N, L)
+    base = torch.randint(-2, 3, shape, generator=g).float().to(TORCH_DT[dname])
+    got, arg = gnnops.scatter(src.cuda(), idx.cuda(), 0, out=base.clone().cuda(), reduce=reduce)
+    exp, earg = oracle.scatter(to_np(src), idx.numpy(), dim=0, out=to_np(base).copy(), reduce=reduce, dtype=dname)
+    assert_bits_equal(to_np(got), exp, "with out")
+    assert np.array_equal(arg.cpu().numpy(), earg)
