@@ -305,8 +305,21 @@ __device__ inline uint32_t f32_order(float v) {
     if (u == 0x80000000u) u = 0u;
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// 16-bit inputs whose positions fit 16 bits (E < 65535: every reference shape) pack into a 32-bit cell — half the LDS per
+// destination, so strips twice as wide. fp16 and bf16 share sign-magnitude order; both widen to fp32 exactly, so the top
+// 16 bits of the fp32 image order bf16 exactly and fp16 after the exact widening (f32_order >> 16 would lose fp16 bits:
+// the image is taken from the 16 stored bits instead).
+__device__ inline uint32_t b16_order(uint16_t u) {
+    if (u == 0x8000u) u = 0u;
+    return (u & 0x8000u) ? (uint16_t)~u : (uint16_t)(u | 0x8000u);
+}
+template <typename CellT, typename T>
+__device__ inline CellT order_image(const T* p, float v) {
+    if constexpr (sizeof(CellT) == 8) return (CellT)f32_order(v);
+    else return (CellT)b16_order(*reinterpret_cast<const uint16_t*>(p));
+}
 
-template <typename T, int R>
+template <typename T, int R, typename CellT>
 __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T* __restrict__ src,
                                                                          const int64_t* __restrict__ index,
                                                                          T* __restrict__ out, int64_t* __restrict__ arg_out,
@@ -316,7 +329,9 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
     static_assert(R == GNNOPS_MIN || R == GNNOPS_MAX, "min / max only");
     constexpr bool IS_MIN = R == GNNOPS_MIN;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* cell = reinterpret_cast<unsigned long long*>(lds_raw);
+    CellT* cell = reinterpret_cast<CellT*>(lds_raw);
+    constexpr int HB = sizeof(CellT) * 4;                     // bits of each half: value image above, position below
+    constexpr CellT LO_MASK = (CellT)(((CellT)1 << HB) - 1);
     constexpr int UNR = 8;
     const int64_t item = xcd_contiguous(blockIdx.x, gridDim.x);
     const int chunk = (int)(item % nchunks);
@@ -330,33 +345,35 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
     const int er = threadIdx.x >> tshift;
     const int rpi = (int)blockDim.x >> tshift;
     const bool col_ok = kk < tc;
-    const unsigned long long EMPTY = IS_MIN ? ~0ull : 0ull;
+    const CellT EMPTY = IS_MIN ? (CellT)~(CellT)0 : (CellT)0;
     // low half: position + 1 (min) or its complement (max); 0 / ~0 stand for "the value already in out", which therefore
     // wins a tie against any source element — the sequential loop only replaces on a strict improvement
-    const uint32_t lo_out = IS_MIN ? 0u : ~0u;
-    auto winner = [&](unsigned long long c) -> int64_t {  // source position that won the cell, -1 if none did
+    const CellT lo_out = IS_MIN ? (CellT)0 : LO_MASK;
+    auto winner = [&](CellT c) -> int64_t {  // source position that won the cell, -1 if none did
         if (c == EMPTY && !init_from_out) return -1;
-        const uint32_t l = IS_MIN ? (uint32_t)c : ~(uint32_t)c;
-        return l == 0u ? -1 : (int64_t)l - 1;
+        const CellT l = (IS_MIN ? c : (CellT)~c) & LO_MASK;
+        return l == 0 ? -1 : (int64_t)l - 1;
     };
 
     if (col_ok) {
         for (int r0 = er; r0 < nloc; r0 += rpi * UNR) {
-            float iv[UNR];
+            T it[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int r = r0 + u * rpi;
                 const int rc = r < nloc ? r : nloc - 1;
-                iv[u] = init_from_out ? Elem<T>::load(out + (b * N + n_lo + rc) * K + k0 + kk) : 0.f;
+                it[u] = init_from_out ? out[(b * N + n_lo + rc) * K + k0 + kk] : T{};
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int r = r0 + u * rpi;
                 if (r < nloc) {
-                    unsigned long long c = EMPTY;
-                    if (init_from_out)  // a NaN in out is never replaced (nothing compares below / above it)
-                        c = (iv[u] != iv[u]) ? (IS_MIN ? 0ull : ~0ull)
-                                             : (((unsigned long long)f32_order(iv[u]) << 32) | lo_out);
+                    CellT c = EMPTY;
+                    if (init_from_out) {  // a NaN in out is never replaced (nothing compares below / above it)
+                        const float iv = Elem<T>::load(&it[u]);
+                        c = (iv != iv) ? (IS_MIN ? (CellT)0 : (CellT)~(CellT)0)
+                                       : (CellT)((order_image<CellT, T>(&it[u], iv) << HB) | lo_out);
+                    }
                     cell[r * tc + kk] = c;
                 }
             }
@@ -369,21 +386,23 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
     if (col_ok) {
         for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
             int64_t nl[UNR];
-            float v[UNR];
+            T vt[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int64_t e = e0 + (int64_t)u * rpi;
                 const int64_t ec = e < E ? e : E - 1;
                 nl[u] = ip[ec * K];
-                v[u] = Elem<T>::load(sp + ec * K);
+                vt[u] = sp[ec * K];
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int64_t e = e0 + (int64_t)u * rpi;
                 const int64_t d = nl[u] - n_lo;
-                if (e >= E || d < 0 || d >= nloc || v[u] != v[u]) continue;
-                const uint32_t lo = IS_MIN ? (uint32_t)e + 1u : ~((uint32_t)e + 1u);
-                const unsigned long long w = ((unsigned long long)f32_order(v[u]) << 32) | lo;
+                const float v = Elem<T>::load(&vt[u]);
+                if (e >= E || d < 0 || d >= nloc || v != v) continue;
+                const CellT pos = (CellT)(e + 1);
+                const CellT lo = IS_MIN ? pos : (CellT)(~pos & LO_MASK);
+                const CellT w = (CellT)((order_image<CellT, T>(&vt[u], v) << HB) | lo);
                 if (IS_MIN) atomicMin(&cell[(int)d * tc + kk], w); else atomicMax(&cell[(int)d * tc + kk], w);
             }
         }
@@ -392,7 +411,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
 
     if (col_ok) {
         for (int r0 = er; r0 < nloc; r0 += rpi * UNR) {
-            unsigned long long c[UNR];
+            CellT c[UNR];
             float val[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -428,8 +447,13 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
 struct LdsGeom { int tc; int64_t rows; int nchunks; };
 constexpr int LDS_MAX_CHUNKS = 16;
 
-inline LdsGeom lds_geometry(int64_t N, int64_t K, int reduce) {
-    const size_t per = (reduce == GNNOPS_SUM || reduce == GNNOPS_MUL) ? 4 : 8;
+// 16-bit min / max with positions below 2^16 - 1 use 32-bit cells (scatter_lds_minmax_kernel)
+inline bool small_cells(int reduce, int elem_bytes, int64_t E) {
+    return (reduce == GNNOPS_MIN || reduce == GNNOPS_MAX) && elem_bytes == 2 && E < 65535;
+}
+
+inline LdsGeom lds_geometry(int64_t N, int64_t K, int reduce, bool small_cell = false) {
+    const size_t per = (reduce == GNNOPS_SUM || reduce == GNNOPS_MUL || small_cell) ? 4 : 8;
     LdsGeom g{0, 0, 0};
     if (N <= 0) return g;
     if ((size_t)N * per <= LDS_BUDGET) {
@@ -465,16 +489,24 @@ int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int
     // init / stream / write-back phases overlap (the kernel needs ~70 VGPRs: one 1024-thread workgroup per CU otherwise)
     const int threads = lds > 80 * 1024 ? LDS_THREADS : lds > 40 * 1024 ? 512 : 256;
     if constexpr (R == GNNOPS_MIN || R == GNNOPS_MAX) {
-        static bool configured_mm = false;
-        if (!configured_mm) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_minmax_kernel<T, R>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
-                return gnnops_check_launch("scatter_lds attribute");
-            configured_mm = true;
-        }
-        hipLaunchKernelGGL((scatter_lds_minmax_kernel<T, R>), dim3((unsigned)(B * strips * g.nchunks)), dim3(threads), lds,
-                           stream, src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks, init_from_out, tshift);
-        return gnnops_check_launch("scatter_lds");
+        auto go = [&](auto cell_tag) -> int {
+            using CellT = decltype(cell_tag);
+            static bool configured_mm = false;
+            if (!configured_mm) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_minmax_kernel<T, R, CellT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
+                    return gnnops_check_launch("scatter_lds attribute");
+                configured_mm = true;
+            }
+            const size_t lds_mm = (size_t)g.rows * g.tc * sizeof(CellT);
+            const int th = lds_mm > 80 * 1024 ? LDS_THREADS : lds_mm > 40 * 1024 ? 512 : 256;
+            hipLaunchKernelGGL((scatter_lds_minmax_kernel<T, R, CellT>), dim3((unsigned)(B * strips * g.nchunks)), dim3(th),
+                               lds_mm, stream, src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks,
+                               init_from_out, tshift);
+            return gnnops_check_launch("scatter_lds");
+        };
+        if (small_cells(R, (int)sizeof(T), E)) return go(uint32_t{});
+        return go((unsigned long long)0);
     }
     hipLaunchKernelGGL((scatter_lds_kernel<T, R>), dim3((unsigned)(B * strips * g.nchunks)), dim3(threads), lds, stream,
                        src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks, init_from_out, tshift);
@@ -507,7 +539,7 @@ int run(const void* src_, const int64_t* index, void* out_, int64_t* arg_out, in
     constexpr bool IS_F32 = sizeof(T) == 4;
     char* w = (char*)workspace;
 
-    if (const LdsGeom g = lds_geometry(N, K, reduce);
+    if (const LdsGeom g = lds_geometry(N, K, reduce, small_cells(reduce, (int)sizeof(T), E));
         g.tc > 0 && B * gnnops_cdiv(K, g.tc) * g.nchunks < ((int64_t)1 << 31) && E < ((int64_t)1 << 31))
         return dispatch_lds<T>(reduce, src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
 
