@@ -348,25 +348,26 @@ template <typename U>
 __global__ __launch_bounds__(256) void select_longrows_kernel(const U* __restrict__ in, const int64_t* __restrict__ index,
                                                               U* __restrict__ out, int64_t B, int64_t N, int64_t KU,
                                                               int64_t E) {
-    constexpr int UNR = 8;
+    constexpr int UNR = 8, SEG = 64 * UNR;  // a wave copies one 512-unit piece of a row per step (few long rows still fill the chip)
     const int lane = threadIdx.x & 63;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t item = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < B * E; item += nwaves) {
-        const int64_t b = item / E, e = item - b * E;
+    const int64_t segs = (KU + SEG - 1) / SEG;
+    for (int64_t item = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < B * E * segs; item += nwaves) {
+        const int64_t row = item / segs, seg = item - row * segs;
+        const int64_t b = row / E, e = row - b * E;
         const U* src = in + (b * N + index[e]) * KU;
-        U* dst = out + item * KU;
-        for (int64_t k0 = lane; k0 < KU; k0 += 64 * UNR) {
-            U v[UNR];
+        U* dst = out + row * KU;
+        const int64_t k0 = seg * SEG + lane;
+        U v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int64_t k = k0 + 64 * u;
-                v[u] = __builtin_nontemporal_load(src + (k < KU ? k : KU - 1));
-            }
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t k = k0 + 64 * u;
+            v[u] = __builtin_nontemporal_load(src + (k < KU ? k : KU - 1));
+        }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int64_t k = k0 + 64 * u;
-                if (k < KU) __builtin_nontemporal_store(v[u], dst + k);
-            }
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t k = k0 + 64 * u;
+            if (k < KU) __builtin_nontemporal_store(v[u], dst + k);
         }
     }
 }
@@ -492,8 +493,8 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
         const uintptr_t al = (uintptr_t)input | (uintptr_t)out | (uintptr_t)rowbytes;
         const int unit = al % 8 == 0 ? 8 : al % 4 == 0 ? 4 : al % 2 == 0 ? 2 : 1;
         if (rowbytes / unit >= LONGROW_MIN_UNITS) {
-            const int lgrid = gnnops_grid_cap(gnnops_cdiv(B * E, 4), 256 * 32);
             const int64_t KU = rowbytes / unit;
+            const int lgrid = gnnops_grid_cap(gnnops_cdiv(B * E * gnnops_cdiv(KU, 512), 4), 256 * 32);
             if (unit == 8)
                 hipLaunchKernelGGL((select_longrows_kernel<uint64_t>), dim3(lgrid), dim3(256), 0, stream, (const uint64_t*)input,
                                    index, (uint64_t*)out, B, N, KU, E);
