@@ -112,6 +112,7 @@ class _Composite(torch.autograd.Function):
       softmax      dx = y * (g - sum_group(g * y))
       log_softmax  dx = g - exp(y) * sum_group(g)
       logsumexp    dx = g[group] * exp(x - out[group])
+      std          dx = g[group] * (x - mean[group]) / ((c' + 1e-6) * out[group]),  c' = max(cnt - ddof, 1); 0 where out == 0
     The group sums and the broadcasts back are our segment-reduce and index_select kernels over the same plan."""
 
     @staticmethod
@@ -126,7 +127,7 @@ class _Composite(torch.autograd.Function):
         plan = ops.get_plan(row, N)
         out = segment._composite(src, plan, dim, N, mode, eps)
         ctx.save_for_backward(src, out, row)
-        ctx.plan, ctx.dim, ctx.mode = plan, dim, mode
+        ctx.plan, ctx.dim, ctx.mode, ctx.param = plan, dim, mode, eps
         return out
 
     @staticmethod
@@ -140,6 +141,14 @@ class _Composite(torch.autograd.Function):
         elif mode == "log_softmax":
             s = ops.scatter(g, plan, dim, None, None, "sum")
             dx = g - out.exp() * ops.index_select(s, dim, row)
+        elif mode == "std":  # out has the group shape; eps carries the unbiased flag (composite.hip: param != 0)
+            mean = ops.scatter(src, plan, dim, None, None, "mean")
+            cnt = (plan.rowptr[1:] - plan.rowptr[:-1]).to(torch.float32)
+            shape = [1] * src.dim()
+            shape[dim] = -1
+            denom = ((cnt - (1.0 if ctx.param != 0 else 0.0)).clamp_(min=1.0) + 1e-6).view(shape) * out.float()
+            scale = torch.where(out != 0, g.float() / denom, torch.zeros_like(denom)).to(src.dtype)
+            dx = ops.index_select(scale, dim, row) * (src - ops.index_select(mean, dim, row))
         else:  # logsumexp: out has the group shape
             dx = ops.index_select(g, dim, row) * (src - ops.index_select(out, dim, row)).exp()
         return dx, None, None, None, None, None

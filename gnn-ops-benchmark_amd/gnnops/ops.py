@@ -364,6 +364,8 @@ def index_select(input, dim, index, plan=None):
     input.size(dim), given or built here when the heuristic above says so): every input row is read once
     and stored to all output rows that select it — N*row reads instead of E*row."""
     _require_gpu(input, index)
+    if index.dtype == torch.int32:  # ATen takes IntTensor indices here; the kernels read int64
+        index = index.long()
     _check_index(index, "index_select")
     if index.dim() > 1:
         raise IndexError("index_select(): Index is supposed to be a vector")
@@ -436,6 +438,8 @@ def index_add_(self, dim, index, source, alpha=1):
         raise NotImplementedError("gnnops.index_add_: self must be contiguous")
     dim = _norm_dim(dim, self.dim(), "index_add_")
     if not is_plan:
+        if index.dtype == torch.int32:  # ATen takes IntTensor indices here; the kernels read int64
+            index = index.long()
         _check_index(index, "index_add_")
         if index.dim() != 1:
             raise IndexError("index_add_(): Index is supposed to be a vector")

@@ -162,4 +162,4 @@ def scatter_logsumexp(src, index, dim=-1, out=None, dim_size=None, eps=1e-12):
 def scatter_std(src, index, dim=-1, out=None, dim_size=None, unbiased=True):
     if out is not None:
         raise NotImplementedError("gnnops.scatter_std: out= is not supported")
-    return _composite(src, index, dim, dim_size, "std", 1.0 if unbiased else 0.0)
+    return _maybe_grad(src, index, dim, dim_size, "std", 1.0 if unbiased else 0.0)

@@ -193,3 +193,17 @@ def test_less_travelled_shapes(gnnops, oracle):
     last = torch.randn(50, 400, generator=g)                      # dim = -1: K = 1
     sd = torch_scatter.scatter_std(last.cuda(), torch.randint(0, 9, (400,), generator=g).cuda(), dim=-1, dim_size=9)
     assert sd.shape == (50, 9) and torch.isfinite(sd).all()
+
+
+def test_int32_indices_where_aten_takes_them(gnnops):
+    """torch.index_select / Tensor.index_add_ accept int32 indices; so do ours (widened once)."""
+    g = torch.Generator().manual_seed(1)
+    table = torch.rand(50, 16, generator=g).cuda()
+    idx = torch.randint(0, 50, (80,), generator=g, dtype=torch.int32).cuda()
+    assert torch.equal(gnnops.index_select(table, 0, idx), table[idx.long()])
+    src = torch.rand(80, 16, generator=g).cuda()
+    out = table.clone()
+    gnnops.index_add_(out, 0, idx, src)
+    ref = table.clone()
+    ref.index_add_(0, idx.long(), src)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)

@@ -213,3 +213,34 @@ def test_composite_backward(gnnops, mode):
     out = fn(dsrc, idx.cuda(), dim=0, dim_size=N)
     (out * w.cuda()).sum().backward()
     np.testing.assert_allclose(dsrc.grad.cpu().numpy(), ref_src.grad.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("unbiased", [True, False])
+def test_scatter_std_backward(gnnops, unbiased):
+    """d scatter_std / d src against torch-CPU autograd of the same per-group formula
+    (sqrt(sum (x - mean)^2 / (max(cnt - ddof, 1) + 1e-6)), composite.hip); groups with one element or none get 0."""
+    import torch_scatter
+
+    g = torch.Generator().manual_seed(29)
+    E, N, K = 500, 40, 8
+    src = torch.randn(E, K, generator=g)
+    idx = torch.randint(0, N, (E,), generator=g)
+    idx[idx == 3] = 4          # group 3 empty
+    idx[idx == 9] = 10
+    idx[0] = 9                 # group 9 has exactly one element (std 0)
+    w = torch.rand(N, K, generator=g)
+    ref_src = src.clone().requires_grad_(True)
+    total = torch.zeros(())
+    for n in range(N):
+        rows = torch.nonzero(idx == n).flatten()
+        if rows.numel() < 2:
+            continue
+        x = ref_src[rows]
+        c = max(rows.numel() - (1 if unbiased else 0), 1) + 1e-6
+        total = total + (((x - x.mean(0)) ** 2).sum(0) / c).sqrt().mul(w[n]).sum()
+    total.backward()
+    dsrc = src.clone().cuda().requires_grad_(True)
+    out = torch_scatter.scatter_std(dsrc, idx.cuda(), dim=0, dim_size=N, unbiased=unbiased)
+    (out * w.cuda()).sum().backward()
+    np.testing.assert_allclose(dsrc.grad.cpu().numpy(), ref_src.grad.numpy(), rtol=5e-5, atol=5e-6)
+    assert (dsrc.grad[0] == 0).all()
