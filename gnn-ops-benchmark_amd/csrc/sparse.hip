@@ -95,7 +95,8 @@ __global__ void reduce_runs_kernel(const T* __restrict__ value, const uint32_t* 
         const int64_t beg = seg_start[u];
         const int64_t end = (u + 1 < count) ? (int64_t)seg_start[u + 1] : nnz;
         float acc = 0.f;
-        for (int64_t p = beg; p < end; ++p) acc = __fadd_rn(acc, Elem<T>::load(value + (int64_t)perm[p] * C + c));
+        for (int64_t p = beg; p < end; ++p)
+            acc = __fadd_rn(acc, Elem<T>::load(value + (perm ? (int64_t)perm[p] : p) * C + c));
         Elem<T>::store(out_value + o, acc);
     }
 }
@@ -179,9 +180,17 @@ extern "C" int gnnops_coalesce(const int64_t* row, const int64_t* col, const voi
     uint64_t* kout = keys_a;
     uint32_t* vin = nullptr;
     uint32_t* vout = vals_a;
+    // scalar fp32 values (the reference's case) ride through the sort as the 32-bit payload themselves, so the run
+    // reduction streams them instead of gathering value[perm[p]]; the stable order of equal keys is the same either way
+    const bool carry_values = value != nullptr && C == 1 && dtype == GNNOPS_F32;
     for (int p = 0; p < passes; ++p) {
-        int rc = (p == 0) ? sortengine::pass_first_u64(kin, kout, vout, nnz, 0, tile_hist, digit_total, tiles, stream)
-                          : sortengine::pass_u64(kin, vin, kout, vout, nnz, 8 * p, tile_hist, digit_total, tiles, stream);
+        int rc;
+        if (p == 0 && carry_values)
+            rc = sortengine::pass_u64(kin, (const uint32_t*)value, kout, vout, nnz, 0, tile_hist, digit_total, tiles, stream);
+        else if (p == 0)
+            rc = sortengine::pass_first_u64(kin, kout, vout, nnz, 0, tile_hist, digit_total, tiles, stream);
+        else
+            rc = sortengine::pass_u64(kin, vin, kout, vout, nnz, 8 * p, tile_hist, digit_total, tiles, stream);
         if (rc) return rc;
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* nv = (vout == vals_a) ? vals_b : vals_a;
@@ -196,8 +205,12 @@ extern "C" int gnnops_coalesce(const int64_t* row, const int64_t* col, const voi
         const int grid = grid_for(nnz * C);
         switch (dtype) {
             case GNNOPS_F32:
-                hipLaunchKernelGGL((reduce_runs_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)value, vin,
-                                   seg_start, d_count, (float*)out_value, nnz, C);
+                if (carry_values)
+                    hipLaunchKernelGGL((reduce_runs_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)vin,
+                                       (const uint32_t*)nullptr, seg_start, d_count, (float*)out_value, nnz, C);
+                else
+                    hipLaunchKernelGGL((reduce_runs_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)value,
+                                       vin, seg_start, d_count, (float*)out_value, nnz, C);
                 break;
             case GNNOPS_F16:
                 hipLaunchKernelGGL((reduce_runs_kernel<__half>), dim3(grid), dim3(256), 0, stream, (const __half*)value, vin,

@@ -45,6 +45,10 @@ __global__ __launch_bounds__(T) void scan_sums_kernel(uint32_t* __restrict__ blo
     if (threadIdx.x == 0) *d_total = (int64_t)carry;  // > 2^32 - 1 is rejected by the host wrapper
 }
 
+// Load-balanced expansion: the T nonzeros of a workgroup own a contiguous run of products; their start offsets sit in
+// LDS and the threads sweep the RUN (thread t takes products t, t + T, ...), finding the owning nonzero by binary search,
+// so the three output streams are written coalesced whatever the row lengths of B (a thread per nonzero writes its
+// products T-strided: 0.51 ms for 8.8M products at the reference shape, 5x the time of everything it moves).
 template <typename V>
 __global__ __launch_bounds__(T) void expand_kernel(const int64_t* __restrict__ rowA, const int64_t* __restrict__ colA,
                                                    const V* __restrict__ valA, int64_t nnzA,
@@ -53,17 +57,36 @@ __global__ __launch_bounds__(T) void expand_kernel(const int64_t* __restrict__ r
                                                    const uint32_t* __restrict__ block_off, int64_t* __restrict__ out_row,
                                                    int64_t* __restrict__ out_col, V* __restrict__ out_val) {
     __shared__ uint32_t s_tmp[T / 64];
+    __shared__ uint32_t s_start[T + 1];   // first product of nonzero t inside the workgroup's run
+    __shared__ int32_t s_bbeg[T];         // where its row of B starts
+    __shared__ int64_t s_row[T];
+    __shared__ float s_va[T];
     const int64_t a = (int64_t)blockIdx.x * T + threadIdx.x;
-    const uint32_t c = a < nnzA ? products_of(colA, rowptrB, a) : 0u;
-    uint32_t p = block_off[blockIdx.x] + block_excl_scan_u32<T / 64>(c, s_tmp, nullptr);
-    if (a >= nnzA) return;
-    const int64_t i = rowA[a], kk = colA[a];
-    const float va = Elem<V>::load(valA + a);
-    for (int32_t j = rowptrB[kk]; j < rowptrB[kk + 1]; ++j, ++p) {
-        const int32_t e = permB[j];
-        out_row[p] = i;
+    uint32_t c = 0;
+    if (a < nnzA) {
+        const int64_t kk = colA[a];
+        s_bbeg[threadIdx.x] = rowptrB[kk];
+        c = (uint32_t)(rowptrB[kk + 1] - rowptrB[kk]);
+        s_row[threadIdx.x] = rowA[a];
+        s_va[threadIdx.x] = Elem<V>::load(valA + a);
+    }
+    uint32_t tot;
+    const uint32_t off = block_excl_scan_u32<T / 64>(c, s_tmp, &tot);
+    s_start[threadIdx.x] = off;
+    if (threadIdx.x == 0) s_start[T] = tot;
+    __syncthreads();
+    const uint32_t base = block_off[blockIdx.x];
+    for (uint32_t q = threadIdx.x; q < tot; q += T) {
+        int lo = 0, hi = T;  // largest t with s_start[t] <= q (empty nonzeros share a start: the last one owns q)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_start[mid] <= q) lo = mid; else hi = mid;
+        }
+        const int32_t e = permB[s_bbeg[lo] + (int32_t)(q - s_start[lo])];
+        const uint32_t p = base + q;
+        out_row[p] = s_row[lo];
         out_col[p] = colB[e];
-        Elem<V>::store(out_val + p, va * Elem<V>::load(valB + e));
+        Elem<V>::store(out_val + p, s_va[lo] * Elem<V>::load(valB + e));
     }
 }
 
