@@ -26,10 +26,12 @@ __device__ inline float key_f32(uint32_t k) {
 constexpr int RADIX = 256;
 
 // THREADS x ROUNDS keys per row at most; LDS: keys u32[CAP] + pos u16[CAP] + per-wave histograms.
+// A "row" here is one SEGMENT of a matrix row: segs == 1 is the whole row of E_total keys; segs == 2 sorts the halves
+// [0, h0) and [h0, E_total) separately (indices stay positions in the whole row) for merge_halves_kernel below.
 template <int THREADS, int ROUNDS>
 __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restrict__ in, float* __restrict__ values,
-                                                            int64_t* __restrict__ indices, int64_t rows, int E,
-                                                            int descending) {
+                                                            int64_t* __restrict__ indices, int64_t rows, int E_total,
+                                                            int descending, int segs, int h0) {
     constexpr int WAVES = THREADS / 64;
     constexpr int CAP = THREADS * ROUNDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char sr_raw[];
@@ -43,8 +45,12 @@ __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restr
     const int wave_base = wave * ROUNDS * 64;
     uint32_t* whist = s_whist + wave * RADIX;
 
-    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
-        const float* src = in + row * E;
+    for (int64_t vrow = blockIdx.x; vrow < rows; vrow += gridDim.x) {
+        const int64_t row = vrow / segs;
+        const int sg = (int)(vrow - row * segs);
+        const int off = sg * h0;
+        const int E = (sg == segs - 1) ? E_total - off : h0;
+        const float* src = in + row * E_total + off;
         uint32_t key[ROUNDS];
         uint32_t px[ROUNDS];  // source position in the high half; the low half is scratch for the ranking
 #pragma unroll
@@ -139,21 +145,22 @@ __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restr
                 }
             }
         }
-        float* vdst = values + row * E;
-        int64_t* idst = indices + row * E;
+        float* vdst = values + row * E_total + off;
+        int64_t* idst = indices + row * E_total + off;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int i = wave_base + r * 64 + lane;
             if (i < E) {
                 vdst[i] = key_f32(descending ? ~key[r] : key[r]);
-                idst[i] = (int64_t)(px[r] >> 16);
+                idst[i] = (int64_t)(px[r] >> 16) + off;
             }
         }
     }
 }
 
 template <int THREADS, int ROUNDS>
-int launch(const float* in, float* values, int64_t* indices, int64_t rows, int E, int descending, hipStream_t stream) {
+int launch(const float* in, float* values, int64_t* indices, int64_t rows, int E, int descending, hipStream_t stream,
+           int segs = 1, int h0 = 0) {
     constexpr int CAP = THREADS * ROUNDS;
     constexpr size_t LDS = (size_t)CAP * 6 + (size_t)(THREADS / 64) * RADIX * 4 + 64 * 4;
     static bool configured = false;
@@ -163,10 +170,62 @@ int launch(const float* in, float* values, int64_t* indices, int64_t rows, int E
             return gnnops_check_launch("sort_rows attribute");
         configured = true;
     }
-    const int grid = gnnops_grid_cap(rows, 256 * 8);
-    hipLaunchKernelGGL((sort_rows_kernel<THREADS, ROUNDS>), dim3(grid), dim3(THREADS), LDS, stream, in, values, indices, rows,
-                       E, descending);
+    const int grid = gnnops_grid_cap(rows * segs, 256 * 8);
+    hipLaunchKernelGGL((sort_rows_kernel<THREADS, ROUNDS>), dim3(grid), dim3(THREADS), LDS, stream, in, values, indices,
+                       rows * segs, E, descending, segs, segs == 1 ? E : h0);
     return gnnops_check_launch("sort_rows");
+}
+
+// Rows of up to twice the on-chip capacity: the two halves come sorted (sort_rows_kernel with segs == 2); a workgroup
+// parks the order images of a whole row in LDS and every element finds its place by ONE binary search in the other half
+// (rank merge): position = own rank + number of smaller elements of the other half — strictly smaller for the first
+// half, smaller-or-equal for the second, which keeps equal keys in source order (stable). Two HBM round trips per element
+// in all, against six-plus radix passes over 64-bit (segment, key) pairs.
+constexpr int MERGE_THREADS = 1024;
+
+__global__ __launch_bounds__(MERGE_THREADS) void merge_halves_kernel(const float* __restrict__ tmp_values,
+                                                                     const int64_t* __restrict__ tmp_indices,
+                                                                     float* __restrict__ values, int64_t* __restrict__ indices,
+                                                                     int64_t rows, int E, int h0, int descending) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mg_raw[];
+    uint32_t* k = reinterpret_cast<uint32_t*>(mg_raw);  // [E] order images (complemented when descending: ascending here)
+    const int h1 = E - h0;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* tv = tmp_values + row * E;
+        const int64_t* ti = tmp_indices + row * E;
+        __syncthreads();
+        for (int i = threadIdx.x; i < E; i += MERGE_THREADS) {
+            const uint32_t key = f32_key(tv[i]);
+            k[i] = descending ? ~key : key;
+        }
+        __syncthreads();
+        for (int i0 = threadIdx.x; i0 < E; i0 += MERGE_THREADS * 4) {
+            int64_t src_idx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // unconditional, clamped: the four index loads are in flight together
+                const int i = i0 + u * MERGE_THREADS;
+                src_idx[u] = ti[i < E ? i : E - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * MERGE_THREADS;
+                if (i >= E) continue;
+                const uint32_t key = k[i];
+                int lo, hi, pos;
+                if (i < h0) {  // count elements of the second half that are strictly smaller
+                    lo = 0; hi = h1;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (k[h0 + mid] < key) lo = mid + 1; else hi = mid; }
+                    pos = i + lo;
+                } else {       // count elements of the first half that are smaller or equal
+                    lo = 0; hi = h0;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (k[mid] <= key) lo = mid + 1; else hi = mid; }
+                    pos = (i - h0) + lo;
+                }
+                values[row * E + pos] = tv[i];
+                indices[row * E + pos] = src_idx[u];
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -189,4 +248,35 @@ extern "C" int gnnops_sort_rows_f32(const float* input, float* values, int64_t* 
     if (E <= 1024 * 8) return launch<1024, 8>(input, values, indices, rows, e, descending, stream);
     if (E <= 1024 * 16) return launch<1024, 16>(input, values, indices, rows, e, descending, stream);
     return launch<1024, 22>(input, values, indices, rows, e, descending, stream);
+}
+
+// Largest row length of the two-half form: the merge keeps one 4-byte order image per key of a row in LDS.
+extern "C" int64_t gnnops_sort_rows2_max_len(void) { return 40000; }
+
+// Rows longer than gnnops_sort_rows_max_len(), up to gnnops_sort_rows2_max_len(): the halves are sorted on chip into (tmp_values,
+// tmp_indices) — each [rows, E], caller-provided — and merged into (values, indices).
+extern "C" int gnnops_sort_rows2_f32(const float* input, float* values, int64_t* indices, float* tmp_values,
+                                     int64_t* tmp_indices, int64_t rows, int64_t E, int descending, gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(rows >= 0 && E >= 0, GNNOPS_EINVAL, "sort_rows2: negative size");
+    GNNOPS_REQUIRE(E > gnnops_sort_rows_max_len() && E <= gnnops_sort_rows2_max_len(), GNNOPS_EUNSUPPORTED,
+                   "sort_rows2: row length %lld outside (%lld, %lld]", (long long)E, (long long)gnnops_sort_rows_max_len(),
+                   (long long)gnnops_sort_rows2_max_len());
+    if (rows == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(input && values && indices && tmp_values && tmp_indices, GNNOPS_EINVAL, "sort_rows2: null pointer");
+    const int e = (int)E, h0 = (e + 1) / 2;
+    int rc;
+    if (h0 <= 1024 * 16) rc = launch<1024, 16>(input, tmp_values, tmp_indices, rows, e, descending, stream, 2, h0);
+    else rc = launch<1024, 22>(input, tmp_values, tmp_indices, rows, e, descending, stream, 2, h0);
+    if (rc != GNNOPS_OK) return rc;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_halves_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return gnnops_check_launch("sort_rows2 attribute");
+        configured = true;
+    }
+    hipLaunchKernelGGL(merge_halves_kernel, dim3(gnnops_grid_cap(rows, 256 * 4)), dim3(MERGE_THREADS), (size_t)E * 4, stream,
+                       tmp_values, tmp_indices, values, indices, rows, e, h0, descending);
+    return gnnops_check_launch("sort_rows2");
 }

@@ -227,9 +227,16 @@ def _sort_rows(mat, descending, out_shape):
     rows, E = mat.shape
     values = torch.empty(out_shape, dtype=torch.float32, device=mat.device)
     indices = torch.empty(out_shape, dtype=torch.int64, device=mat.device)
+    L = _lib.load()
     with torch.cuda.device(mat.device):
-        check(_lib.load().gnnops_sort_rows_f32(mat.data_ptr(), values.data_ptr(), indices.data_ptr(), rows, E,
-                                               1 if descending else 0, _stream()), "sort_rows")
+        if E <= L.gnnops_sort_rows_max_len():
+            check(L.gnnops_sort_rows_f32(mat.data_ptr(), values.data_ptr(), indices.data_ptr(), rows, E,
+                                         1 if descending else 0, _stream()), "sort_rows")
+        else:  # up to twice the on-chip capacity: halves sorted on chip, then one rank merge
+            tv = torch.empty((rows, E), dtype=torch.float32, device=mat.device)
+            ti = torch.empty((rows, E), dtype=torch.int64, device=mat.device)
+            check(L.gnnops_sort_rows2_f32(mat.data_ptr(), values.data_ptr(), indices.data_ptr(), tv.data_ptr(), ti.data_ptr(),
+                                          rows, E, 1 if descending else 0, _stream()), "sort_rows2")
     return values, indices
 
 
@@ -251,7 +258,7 @@ def sort(input, dim=-1, descending=False, stable=False):
     if sd >= 4 and B * K != 1:
         raise NotImplementedError(f"gnnops.sort: {input.dtype} is sorted for 1-D tensors only")
     L = _lib.load()
-    if input.dtype == torch.float32 and 32 <= E <= L.gnnops_sort_rows_max_len() and B * K > 1:
+    if input.dtype == torch.float32 and 32 <= E <= L.gnnops_sort_rows2_max_len() and B * K > 1:
         # rows that fit in LDS are sorted on chip; along dim 0 of a matrix via our tiled transposes
         if K == 1:
             return _sort_rows(input.view(B, E), descending, input.shape)

@@ -207,6 +207,11 @@ int gnnops_sort(const void* input, void* values, int64_t* indices, int64_t B, in
 int64_t gnnops_sort_rows_max_len(void);
 int gnnops_sort_rows_f32(const float* input, float* values, int64_t* indices, int64_t rows, int64_t E,
                          int descending, gnnops_stream_t stream);
+int64_t gnnops_sort_rows2_max_len(void);
+/* Rows longer than gnnops_sort_rows_max_len(), up to gnnops_sort_rows2_max_len() (the reference's (28200, 28200) sort): halves sorted on chip into the caller's
+ * (tmp_values, tmp_indices) — each [rows, E] — then rank-merged into (values, indices). Same ordering conventions. */
+int gnnops_sort_rows2_f32(const float* input, float* values, int64_t* indices, float* tmp_values, int64_t* tmp_indices,
+                          int64_t rows, int64_t E, int descending, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch_sparse.coalesce(index, value, m, n, op="add") / Tensor.coalesce()

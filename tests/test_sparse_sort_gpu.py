@@ -183,7 +183,8 @@ def test_sort_dtypes_and_descending(gnnops, dt, descending):
     assert torch.equal(v.cpu(), ev) and torch.equal(i.cpu(), ei)
 
 
-@pytest.mark.parametrize("rows,E", [(300, 1000), (50, 4096), (40, 8000), (20, 16384), (6, 20000), (3, 22528), (5000, 33), (7, 1025)])
+@pytest.mark.parametrize("rows,E", [(300, 1000), (50, 4096), (40, 8000), (20, 16384), (6, 20000), (3, 22528), (5000, 33), (7, 1025),
+                                    (5, 22529), (4, 28200), (3, 32769), (2, 40000), (2, 40001)])  # two halves + rank merge; the last: HBM passes
 @pytest.mark.parametrize("descending", [False, True])
 def test_sort_rows_on_chip(gnnops, rows, E, descending):
     """Rows that fit in LDS take the on-chip kernel (last dim), and dim 0 of a matrix goes through our transposes:
