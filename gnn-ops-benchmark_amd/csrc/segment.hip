@@ -156,20 +156,21 @@ __global__ __launch_bounds__(256) void seg_elems_kernel(const T* __restrict__ sr
 // kernel gathers 2-byte values from HBM; here a workgroup parks TB whole rows src[b, :] in LDS with coalesced loads and
 // every thread walks the segment of its destination once for all TB rows, reading the values from LDS. No atomics:
 // contributions are combined in ascending position, as everywhere else.
-constexpr int K1_THREADS = 512;
+constexpr int K1_THREADS = 512, K1_MAX_THREADS = 1024;
 constexpr int K1_MAX_TB = 4;
 constexpr int K1_U = 4;  // destinations per thread per sweep
-constexpr size_t K1_LDS_BYTES = 64 * 1024;   // largest row taken
+constexpr size_t K1_LDS_BYTES = 156 * 1024;  // largest row taken
 constexpr size_t K1_LDS_TARGET = 40 * 1024;  // LDS per workgroup aimed at
 
 template <typename T, int R>
-__global__ __launch_bounds__(K1_THREADS) void seg_k1_kernel(const T* __restrict__ src, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(K1_MAX_THREADS) void seg_k1_kernel(const T* __restrict__ src, const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ perm, T* __restrict__ out,
                                                             int64_t* __restrict__ arg_out, int64_t B, int64_t E, int64_t N,
                                                             int TB, int init_from_out, int is_mean) {
     constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
     extern __shared__ __attribute__((aligned(16))) unsigned char k1_raw[];
     T* rows = reinterpret_cast<T*>(k1_raw);  // [TB][E]
+    const int NT = (int)blockDim.x;  // 512, or 1024 for rows that leave room for one workgroup per CU only
     const int64_t b0 = (int64_t)blockIdx.x * TB;
     const int tb = (int)((B - b0 < TB) ? (B - b0) : TB);
     const T* sb = src + b0 * E;
@@ -180,25 +181,25 @@ __global__ __launch_bounds__(K1_THREADS) void seg_k1_kernel(const T* __restrict_
         const u32x4* sv = reinterpret_cast<const u32x4*>(sb);
         u32x4* dv = reinterpret_cast<u32x4*>(rows);
         int64_t i = threadIdx.x;
-        for (; i + 3 * K1_THREADS < nvec; i += 4 * K1_THREADS) {  // four 16-B loads in flight per thread
-            const u32x4 a = sv[i], b = sv[i + K1_THREADS], c = sv[i + 2 * K1_THREADS], d = sv[i + 3 * K1_THREADS];
-            dv[i] = a; dv[i + K1_THREADS] = b; dv[i + 2 * K1_THREADS] = c; dv[i + 3 * K1_THREADS] = d;
+        for (; i + 3 * NT < nvec; i += 4 * NT) {  // four 16-B loads in flight per thread
+            const u32x4 a = sv[i], b = sv[i + NT], c = sv[i + 2 * NT], d = sv[i + 3 * NT];
+            dv[i] = a; dv[i + NT] = b; dv[i + 2 * NT] = c; dv[i + 3 * NT] = d;
         }
-        for (; i < nvec; i += K1_THREADS) dv[i] = sv[i];
-        for (int64_t j = nvec * PER + threadIdx.x; j < nelem; j += K1_THREADS) rows[j] = sb[j];
+        for (; i < nvec; i += NT) dv[i] = sv[i];
+        for (int64_t j = nvec * PER + threadIdx.x; j < nelem; j += NT) rows[j] = sb[j];
     } else {
-        for (int64_t i = threadIdx.x; i < nelem; i += K1_THREADS) rows[i] = sb[i];
+        for (int64_t i = threadIdx.x; i < nelem; i += NT) rows[i] = sb[i];
     }
     __syncthreads();
 
     // K1_U destinations per thread at a time, so that the row-pointer, out and perm loads of all of them are in flight
     // together (loads are unconditional on clamped indices: a load under a branch is waited for inside the branch)
-    for (int64_t n0 = threadIdx.x; n0 < N; n0 += (int64_t)K1_THREADS * K1_U) {
+    for (int64_t n0 = threadIdx.x; n0 < N; n0 += (int64_t)NT * K1_U) {
         int32_t beg[K1_U], end[K1_U];
         int64_t nn[K1_U];
 #pragma unroll
         for (int u = 0; u < K1_U; ++u) {
-            const int64_t n = n0 + (int64_t)u * K1_THREADS;
+            const int64_t n = n0 + (int64_t)u * NT;
             nn[u] = n < N ? n : N - 1;
             beg[u] = rowptr[nn[u]];
             end[u] = rowptr[nn[u] + 1];
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(K1_THREADS) void seg_k1_kernel(const T* __restrict_
         int32_t maxlen = 0;
 #pragma unroll
         for (int u = 0; u < K1_U; ++u) {
-            if (n0 + (int64_t)u * K1_THREADS >= N) end[u] = beg[u];  // past the end: nothing to do, nothing stored
+            if (n0 + (int64_t)u * NT >= N) end[u] = beg[u];  // past the end: nothing to do, nothing stored
             maxlen = (end[u] - beg[u] > maxlen) ? end[u] - beg[u] : maxlen;
         }
         for (int32_t sidx = 0; sidx < maxlen; ++sidx) {
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(K1_THREADS) void seg_k1_kernel(const T* __restrict_
         }
 #pragma unroll
         for (int u = 0; u < K1_U; ++u) {
-            const int64_t n = n0 + (int64_t)u * K1_THREADS;
+            const int64_t n = n0 + (int64_t)u * NT;
             if (n >= N) continue;
             const int32_t len = end[u] - beg[u];
             if (len == 0 && init_from_out && !(IS_ARG && arg_out)) continue;  // the out row stays as it is
@@ -281,9 +282,17 @@ int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void
         if (tb < 1) tb = 1;
         if (tb > K1_MAX_TB) tb = K1_MAX_TB;
         if (tb > B) tb = (int)B;
-        hipLaunchKernelGGL((seg_k1_kernel<T, R>), dim3((unsigned)gnnops_cdiv(B, tb)), dim3(K1_THREADS),
-                           (size_t)tb * E * sizeof(T), stream, (const T*)src, rowptr, perm, (T*)out, arg_out, B, E, N, tb,
-                           init_from_out, is_mean);
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_k1_kernel<T, R>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BYTES) != hipSuccess)
+                return gnnops_check_launch("seg_k1 attribute");
+            configured = true;
+        }
+        const size_t lds = (size_t)tb * E * sizeof(T);
+        hipLaunchKernelGGL((seg_k1_kernel<T, R>), dim3((unsigned)gnnops_cdiv(B, tb)),
+                           dim3(lds > 80 * 1024 ? K1_MAX_THREADS : K1_THREADS), lds, stream, (const T*)src, rowptr, perm,
+                           (T*)out, arg_out, B, E, N, tb, init_from_out, is_mean);
         return gnnops_check_launch("segment_reduce");
     }
     if (K % VEC == 0 && aligned) {

@@ -331,7 +331,7 @@ def test_config1_scatter_add(gnnops, oracle):
 
 @pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max", "mul"])
-@pytest.mark.parametrize("B,E,N", [(37, 1001, 300), (5, 4096, 4096), (300, 600, 256)])
+@pytest.mark.parametrize("B,E,N", [(37, 1001, 300), (5, 4096, 4096), (300, 600, 256), (3, 70000, 20000)])  # last: one 1024-thread workgroup per CU
 def test_batched_k1_rows_in_lds(gnnops, oracle, B, E, N, reduce, dname):
     """src [B, E] reduced along dim 1 with ONE row index for every b (layout R, K == 1): the LDS-staged kernel of
     segment.hip (whole rows parked on chip, no atomics) — bit-exact against the sequential oracle, ragged last tile of
