@@ -186,6 +186,98 @@ __global__ __launch_bounds__(GL_THREADS) void gather_lds_kernel(const U* __restr
     }
 }
 
+// index_select along the last dim of a matrix (K == 1) with ONE index for every row — the reference's dim-1 sweeps
+// (benchmark_native_index_select.py:61-67): a workgroup parks TB whole input rows in LDS and every index value it loads
+// serves all TB rows, so the index is read B / TB times instead of B times (it is as large as a row of the output).
+constexpr int SK1_THREADS = 512, SK1_MAX_TB = 4;
+constexpr size_t SK1_LDS_TARGET = 64 * 1024;
+
+template <typename U>
+__global__ __launch_bounds__(SK1_THREADS) void select_k1_kernel(const U* __restrict__ in, const int64_t* __restrict__ index,
+                                                                U* __restrict__ out, int64_t B, int64_t N, int64_t E,
+                                                                int TB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk1_raw[];
+    U* rows = reinterpret_cast<U*>(sk1_raw);  // [TB][N]
+    constexpr int UNR = 8;
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+    const int tb = (int)((B - b0 < TB) ? (B - b0) : TB);
+    const U* sb = in + b0 * N;
+    const int64_t nelem = (int64_t)tb * N;  // the tb rows are contiguous
+    if ((((uintptr_t)sb) & 15) == 0) {
+        constexpr int PER = 16 / (int)sizeof(U);
+        const int64_t nvec = nelem / PER;
+        const u32x4* sv = reinterpret_cast<const u32x4*>(sb);
+        u32x4* dv = reinterpret_cast<u32x4*>(rows);
+        int64_t i = threadIdx.x;
+        for (; i + 3 * SK1_THREADS < nvec; i += 4 * SK1_THREADS) {
+            const u32x4 a = sv[i], c = sv[i + SK1_THREADS], d = sv[i + 2 * SK1_THREADS], f = sv[i + 3 * SK1_THREADS];
+            dv[i] = a; dv[i + SK1_THREADS] = c; dv[i + 2 * SK1_THREADS] = d; dv[i + 3 * SK1_THREADS] = f;
+        }
+        for (; i < nvec; i += SK1_THREADS) dv[i] = sv[i];
+        for (int64_t j = nvec * PER + threadIdx.x; j < nelem; j += SK1_THREADS) rows[j] = sb[j];
+    } else {
+        for (int64_t i = threadIdx.x; i < nelem; i += SK1_THREADS) rows[i] = sb[i];
+    }
+    __syncthreads();
+    U* ob = out + b0 * E;
+    if constexpr (sizeof(U) == 2) {
+        // 16-bit elements, even E: a lane produces TWO neighbouring outputs per step — one 16-B load of two indices, one
+        // 4-byte store per row — instead of 2-byte stores (sub-dword stores cost as much address work as dword ones)
+        if ((E & 1) == 0 && (((uintptr_t)ob) & 3) == 0 && (((uintptr_t)index) & 15) == 0) {
+            const int64_t E2 = E >> 1;
+            const longlong2* ix2 = reinterpret_cast<const longlong2*>(index);
+            for (int64_t p0 = threadIdx.x; p0 < E2; p0 += (int64_t)SK1_THREADS * UNR) {
+                longlong2 n2[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int64_t p = p0 + (int64_t)u * SK1_THREADS;
+                    n2[u] = ix2[p < E2 ? p : E2 - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int64_t p = p0 + (int64_t)u * SK1_THREADS;
+                    if (p >= E2) continue;
+#pragma unroll
+                    for (int t = 0; t < SK1_MAX_TB; ++t) {
+                        if (t < tb) {
+                            const uint32_t lo = rows[(int64_t)t * N + n2[u].x], hi = rows[(int64_t)t * N + n2[u].y];
+                            reinterpret_cast<uint32_t*>(ob + (int64_t)t * E)[p] = lo | (hi << 16);
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+    for (int64_t e0 = threadIdx.x; e0 < E; e0 += (int64_t)SK1_THREADS * UNR) {
+        int64_t n[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {  // unconditional, clamped: the eight index loads are in flight together
+            const int64_t e = e0 + (int64_t)u * SK1_THREADS;
+            n[u] = index[e < E ? e : E - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t e = e0 + (int64_t)u * SK1_THREADS;
+            if (e >= E) continue;
+#pragma unroll
+            for (int t = 0; t < SK1_MAX_TB; ++t)
+                if (t < tb) ob[(int64_t)t * E + e] = rows[(int64_t)t * N + n[u]];
+        }
+    }
+}
+
+template <typename U>
+int launch_select_k1(const void* in, const int64_t* index, void* out, int64_t B, int64_t N, int64_t E, hipStream_t stream) {
+    int tb = (int)(SK1_LDS_TARGET / ((size_t)N * sizeof(U)));
+    if (tb < 1) tb = 1;
+    if (tb > SK1_MAX_TB) tb = SK1_MAX_TB;
+    if (tb > B) tb = (int)B;
+    hipLaunchKernelGGL((select_k1_kernel<U>), dim3((unsigned)gnnops_cdiv(B, tb)), dim3(SK1_THREADS), (size_t)tb * N * sizeof(U),
+                       stream, (const U*)in, index, (U*)out, B, N, E, tb);
+    return gnnops_check_launch("index_select");
+}
+
 inline int gather_lds_width(int64_t N, int64_t K, int64_t E, int elem_bytes) {
     if (N <= 0 || (size_t)N * elem_bytes > GL_BUDGET) return 0;
     int64_t tc = (int64_t)(GL_BUDGET / ((size_t)N * elem_bytes));
@@ -479,6 +571,16 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
         hipLaunchKernelGGL((select_rows_kernel<true, true, ROWS_IN_FLIGHT>), dim3(sgrid), dim3(256), 0, stream,
                            (const char*)input, index, (char*)out, B, N, E, rowbytes, g.gshift, g.chunks);
     } else {
+        // K == 1 with a batch of rows that fit 64 KiB of LDS: rows parked on chip, the index shared by TB rows
+        if (K == 1 && B > 1 && N >= 512 && E >= 256 && (size_t)N * elem_bytes <= 64 * 1024 && E * 32 >= N * elem_bytes &&
+            gnnops_cdiv(B, 1) < ((int64_t)1 << 31)) {
+            switch (elem_bytes) {
+                case 1: return launch_select_k1<uint8_t>(input, index, out, B, N, E, stream);
+                case 2: return launch_select_k1<uint16_t>(input, index, out, B, N, E, stream);
+                case 4: return launch_select_k1<uint32_t>(input, index, out, B, N, E, stream);
+                default: return launch_select_k1<uint64_t>(input, index, out, B, N, E, stream);
+            }
+        }
         // a row index with K > 1 is already coalesced along k in the element kernel; LDS staging pays for K == 1 rows
         if (const int tc = gather_lds_width(N, K, E, elem_bytes);
             tc > 0 && K * elem_bytes <= 8 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31)) {
