@@ -1,0 +1,50 @@
+"""The ops are capturable into HIP graphs (torch.cuda.CUDAGraph): nothing behind the C ABI allocates or synchronises, and
+every launch goes to the stream the caller hands over. A launch-bound step — a small one-shot scatter is nine kernels —
+is replayed as one graph launch; the replay must see new input values and reproduce the eager result bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gnnops():
+    import gnnops as g
+
+    g.load_library()
+    return g
+
+
+def test_scatter_index_select_addmm_in_a_graph(gnnops):
+    N, E, D = 3000, 20000, 64
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    src = torch.rand(E, D, generator=gen, device="cuda")
+    idx = torch.randint(0, N, (E,), generator=gen, device="cuda")
+    w = torch.rand(D, D, generator=gen, device="cuda").to(torch.bfloat16)
+    gnnops.set_plan_cache(False)   # one-shot forms: the whole op is device work on the current stream
+    try:
+        def step():
+            agg = gnnops.scatter_add(src, idx, 0, dim_size=N)           # partition + bucketed reduce
+            mn, arg = gnnops.scatter_min(src, idx, 0, dim_size=N)
+            sel = gnnops.index_select(agg, 0, idx)
+            y = gnnops.addmm(agg.to(torch.bfloat16), agg.to(torch.bfloat16), w)
+            return agg, mn, arg, sel, y
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                  # warm-up outside capture (one-time attributes)
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = step()
+        for trial in range(2):
+            src.copy_(torch.rand(E, D, generator=gen, device="cuda"))   # new values in the captured buffers
+            idx.copy_(torch.randint(0, N, (E,), generator=gen, device="cuda"))
+            graph.replay()
+            torch.cuda.synchronize()
+            eager = step()
+            for got, exp in zip(outs, eager):
+                assert torch.equal(got, exp), trial
+    finally:
+        gnnops.set_plan_cache(True)
