@@ -378,6 +378,14 @@ def extra_ops(torch, gnnops, src, index, N, E, D):
         rec("index_select_pull", lambda: gnnops.index_select(table, 0, index), "index_select")
     finally:
         _ops._PUSH_MIN_TABLE_BYTES = saved
+    del table, plan
+    # destination-sorted variant (real edge_index is usually coalesced): the same cold op on an ascending
+    # index, and torch_scatter.segment_coo for a caller that KNOWS it is sorted (no partition at all)
+    sorted_index = torch.sort(index).values
+    rec("scatter_add_cold_sorted_index", lambda: gnnops.scatter_add(src, sorted_index, 0, dim_size=N), "scatter_add")
+    from gnnops import segment as _seg
+
+    rec("segment_coo_sorted_index", lambda: _seg.segment_coo(src, sorted_index, dim_size=N, reduce="sum"), "scatter_add")
     return res
 
 
