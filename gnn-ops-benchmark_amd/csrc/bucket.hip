@@ -18,6 +18,7 @@
 // holds the running value exactly, i.e. fp32 for every reduce and any type for min / max; the host side (ops.py) keeps
 // 16-bit sums / means / products on the plan path, where the fp32 accumulator is rounded once.
 #include "common.h"
+#include "hub.h"
 #include "sort_engine.h"
 
 namespace {
@@ -140,9 +141,11 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
                                                                 const int32_t* __restrict__ bptr, T* __restrict__ out,
                                                                 int64_t* __restrict__ arg_out, int64_t E, int64_t K,
                                                                 int64_t N, int64_t NB, int gshift, int kchunks,
-                                                                int init_from_out, int is_mean) {
+                                                                int init_from_out, int is_mean, hub::Ws hw, int hub_on) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
+    __shared__ uint32_t s_deg[BROWS];  // hub detection: contributions per destination of a large bucket
+    __shared__ uint8_t s_hub[BROWS];   // 1: set aside for the hub pass (hub.h)
     __shared__ int32_t s_perm[CAP];
     __shared__ uint32_t s_whist[WAVES * 256];
     __shared__ int32_t s_rowptr[BROWS + 1];
@@ -156,6 +159,20 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
 
     for (int64_t bucket = blockIdx.x; bucket < NB; bucket += gridDim.x) {
         const int32_t bbeg = bptr[bucket], bend = bptr[bucket + 1];
+        __syncthreads();  // the previous bucket's readers are done with s_hub
+        s_hub[tid] = 0;
+        if (hub_on && bend - bbeg > hub::T_HUB) {  // only such a bucket can hold a hub: count per destination first
+            s_deg[tid] = 0;
+            __syncthreads();
+            for (int32_t i = bbeg + tid; i < bend; i += THREADS) atomicAdd(&s_deg[keys[i] & (BROWS - 1)], 1u);
+            __syncthreads();
+            const uint32_t is_hub = s_deg[tid] > (uint32_t)hub::T_HUB ? 1u : 0u;
+            const uint32_t rank = block_excl_scan_u32<WAVES>(is_hub, s_tmp, nullptr);  // the smallest ids first: deterministic
+            if (is_hub && rank < (uint32_t)hub::MAX_PER_BUCKET && bucket * BROWS + tid < N) {
+                s_hub[tid] = 1;
+                hub::append(hw, (int)(bucket * BROWS + tid), bbeg, bend, (int)s_deg[tid]);
+            }
+        }
         for (int32_t cbeg = bbeg;; cbeg += CAP) {
             const bool first = cbeg == bbeg;
             const bool last = cbeg + CAP >= bend;
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
                 const int chunk = item >> BSHIFT;
                 const int64_t nrow = bucket * BROWS + dloc;
                 const int64_t col = ((int64_t)chunk * G + gl) * VEC;
-                if (nrow >= N || col >= K) continue;
+                if (nrow >= N || col >= K || s_hub[dloc]) continue;  // hubs: neither reduced nor stored here
                 const int32_t beg = s_rowptr[dloc], end = s_rowptr[dloc + 1];
                 // nothing to fold in and the row already holds the running value: leave it (unless this visit must still
                 // write an arg row, zero-fill an empty min / max group or divide a mean)
@@ -307,27 +324,42 @@ __global__ __launch_bounds__(THREADS) void bucket_push_kernel(const char* __rest
 template <typename T, int R>
 int launch_bucket(const void* src, const uint32_t* keys, const uint32_t* vals, const int32_t* bptr, void* out,
                   int64_t* arg_out, int64_t E, int64_t K, int64_t N, int64_t NB, int init_from_out, int is_mean,
-                  hipStream_t stream) {
+                  hipStream_t stream, void* hub_ws, size_t hub_ws_bytes) {
     constexpr int VEC = Elem<T>::VEC;
     const int64_t vecs = K / VEC;
     int gshift = 0;
     while ((1 << gshift) < vecs && gshift < 6) ++gshift;
     const int kchunks = (int)gnnops_cdiv(vecs, (int64_t)1 << gshift);
     const int grid = gnnops_grid_cap(NB, 256 * 16);
+    constexpr bool want_arg = (R == GNNOPS_MIN || R == GNNOPS_MAX);
+    hub::Ws hw{};
+    int hub_on = 0;
+    if (hub_ws && E > hub::T_HUB) {
+        const hub::Layout hl = hub::layout(E, K, want_arg);
+        if (hub_ws_bytes >= hl.total) {
+            hw = hub::make_ws(hub_ws, hl, E, want_arg);
+            if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+            hub_on = 1;
+        }
+    }
     hipLaunchKernelGGL((bucket_reduce_kernel<T, R>), dim3(grid), dim3(THREADS), 0, stream, (const T*)src, keys, vals, bptr,
-                       (T*)out, arg_out, E, K, N, NB, gshift, kchunks, init_from_out, is_mean);
+                       (T*)out, arg_out, E, K, N, NB, gshift, kchunks, init_from_out, is_mean, hw, hub_on);
+    if (hub_on)
+        hub::launch_pass<T, R, true>((const T*)src, nullptr, keys, vals, (T*)out, arg_out, hw, E, K, gshift, kchunks,
+                                     init_from_out, is_mean, stream);
     return gnnops_check_launch("scatter_rows_oneshot");
 }
 
 template <typename T>
 int dispatch_bucket(int reduce, const void* src, const uint32_t* keys, const uint32_t* vals, const int32_t* bptr, void* out,
-                    int64_t* arg_out, int64_t E, int64_t K, int64_t N, int64_t NB, int init_from_out, hipStream_t stream) {
+                    int64_t* arg_out, int64_t E, int64_t K, int64_t N, int64_t NB, int init_from_out, hipStream_t stream,
+                    void* hw = nullptr, size_t hb = 0) {
     switch (reduce) {
-        case GNNOPS_SUM: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream);
-        case GNNOPS_MEAN: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 1, stream);
-        case GNNOPS_MUL: return launch_bucket<T, GNNOPS_MUL>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream);
-        case GNNOPS_MIN: return launch_bucket<T, GNNOPS_MIN>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream);
-        case GNNOPS_MAX: return launch_bucket<T, GNNOPS_MAX>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream);
+        case GNNOPS_SUM: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream, hw, hb);
+        case GNNOPS_MEAN: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 1, stream, hw, hb);
+        case GNNOPS_MUL: return launch_bucket<T, GNNOPS_MUL>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream, hw, hb);
+        case GNNOPS_MIN: return launch_bucket<T, GNNOPS_MIN>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream, hw, hb);
+        case GNNOPS_MAX: return launch_bucket<T, GNNOPS_MAX>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream, hw, hb);
     }
     gnnops_set_error("scatter_rows_oneshot: unknown reduce %d", reduce);
     return GNNOPS_EINVAL;
@@ -452,6 +484,13 @@ extern "C" int gnnops_bucket_layout(int64_t E, int64_t N, size_t* keys_offset, s
 // filled for the same (E, N). src [E, K], out [N, K]; arg_out [N, K] int64 or NULL (min / max only).
 extern "C" int gnnops_bucket_reduce(const void* src, const void* workspace, void* out, int64_t* arg_out, int64_t E, int64_t K,
                                     int64_t N, int dtype, int reduce, int init_from_out, gnnops_stream_t s) {
+    return gnnops_bucket_reduce_hubs(src, workspace, out, arg_out, E, K, N, dtype, reduce, init_from_out, nullptr, 0, s);
+}
+
+// The same with hubs (more than 8192 contributions to one destination) set aside and reduced piecewise: hub.h.
+extern "C" int gnnops_bucket_reduce_hubs(const void* src, const void* workspace, void* out, int64_t* arg_out, int64_t E,
+                                         int64_t K, int64_t N, int dtype, int reduce, int init_from_out, void* hub_workspace,
+                                         size_t hub_workspace_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(E >= 0 && K >= 0 && N >= 0, GNNOPS_EINVAL, "bucket_reduce: negative size");
     GNNOPS_REQUIRE(!(reduce == GNNOPS_MEAN && init_from_out), GNNOPS_EINVAL, "bucket_reduce: mean cannot start from out");
@@ -472,9 +511,9 @@ extern "C" int gnnops_bucket_reduce(const void* src, const void* workspace, void
     const int32_t* bptr = (const int32_t*)(w + l.bptr);
     const int64_t NB = gnnops_cdiv(N, BROWS);
     switch (dtype) {
-        case GNNOPS_F32: return dispatch_bucket<float>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream);
-        case GNNOPS_F16: return dispatch_bucket<__half>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream);
-        default: return dispatch_bucket<__hip_bfloat16>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream);
+        case GNNOPS_F32: return dispatch_bucket<float>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes);
+        case GNNOPS_F16: return dispatch_bucket<__half>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes);
+        default: return dispatch_bucket<__hip_bfloat16>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes);
     }
 }
 

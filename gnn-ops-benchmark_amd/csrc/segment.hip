@@ -12,6 +12,7 @@
 // Algorithmic bytes per destination row: deg*K*s (src) + deg*8 (index) + K*s (out)
 // [+ K*8 arg_out]. Extra real traffic: rowptr 4 B/row and perm 4 B/edge instead of the 8-B index.
 #include "common.h"
+#include "hub.h"
 
 namespace {
 
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
                                                        const int32_t* __restrict__ perm, T* __restrict__ out,
                                                        int64_t* __restrict__ arg_out, int64_t B, int64_t E, int64_t K,
                                                        int64_t N, int gshift, int kchunks, int init_from_out,
-                                                       int is_mean) {
+                                                       int is_mean, hub::Ws hw, int hub_on) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
     const int G = 1 << gshift;
@@ -45,6 +46,10 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
         if (col >= K) continue;
         const int32_t beg = rowptr[n], end = rowptr[n + 1];
         if (beg == end && init_from_out && !(IS_ARG && arg_out)) continue;  // nothing to fold in: the out row stays as it is
+        if (hub_on && end - beg > hub::T_HUB) {  // a hub (hub.h): set aside for the hub pass, neither reduced nor stored here
+            if (gl == 0 && chunk == 0) hub::append(hw, (int)n, beg, end, end - beg);
+            continue;
+        }
         const T* srcb = src + (b * E) * K + col;
         const int64_t oidx = (b * N + n) * K + col;
 
@@ -270,7 +275,8 @@ __global__ __launch_bounds__(K1_MAX_THREADS) void seg_k1_kernel(const T* __restr
 
 template <typename T, int R>
 int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void* out, int64_t* arg_out, int64_t B,
-               int64_t E, int64_t K, int64_t N, int init_from_out, int is_mean, hipStream_t stream) {
+               int64_t E, int64_t K, int64_t N, int init_from_out, int is_mean, hipStream_t stream, void* hub_ws = nullptr,
+               size_t hub_ws_bytes = 0) {
     constexpr int VEC = Elem<T>::VEC;
     const bool aligned = ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
                          (arg_out == nullptr || (uintptr_t)arg_out % 16 == 0);
@@ -304,8 +310,24 @@ int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void
         const int64_t items = B * kchunks * N;
         const int64_t groups_per_block = 256 >> gshift;
         int grid = gnnops_grid_cap(gnnops_cdiv(items, groups_per_block), 256 * 64);
+        // hubs (hub.h) are set aside when the caller brought the workspace for them: plan form, one matrix
+        constexpr bool IS_ARG_R = (R == GNNOPS_MIN || R == GNNOPS_MAX);
+        const bool want_arg = IS_ARG_R;
+        hub::Ws hw{};
+        int hub_on = 0;
+        if (hub_ws && perm && B == 1 && E > hub::T_HUB) {
+            const hub::Layout hl = hub::layout(E, K, want_arg);
+            if (hub_ws_bytes >= hl.total) {
+                hw = hub::make_ws(hub_ws, hl, E, want_arg);
+                if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+                hub_on = 1;
+            }
+        }
         hipLaunchKernelGGL((seg_rows_kernel<T, R>), dim3(grid), dim3(256), 0, stream, (const T*)src, rowptr, perm,
-                           (T*)out, arg_out, B, E, K, N, gshift, kchunks, init_from_out, is_mean);
+                           (T*)out, arg_out, B, E, K, N, gshift, kchunks, init_from_out, is_mean, hw, hub_on);
+        if (hub_on)
+            hub::launch_pass<T, R, false>((const T*)src, perm, nullptr, nullptr, (T*)out, arg_out, hw, E, K, gshift, kchunks,
+                                          init_from_out, is_mean, stream);
     } else {
         int grid = gnnops_grid_cap(gnnops_cdiv(B * N * K, 256), 256 * 32);
         hipLaunchKernelGGL((seg_elems_kernel<T, R>), dim3(grid), dim3(256), 0, stream, (const T*)src, rowptr, perm,
@@ -317,13 +339,13 @@ int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void
 template <typename T>
 int dispatch_reduce(int reduce, const void* src, const int32_t* rowptr, const int32_t* perm, void* out,
                     int64_t* arg_out, int64_t B, int64_t E, int64_t K, int64_t N, int init_from_out,
-                    hipStream_t stream) {
+                    hipStream_t stream, void* hw = nullptr, size_t hb = 0) {
     switch (reduce) {
-        case GNNOPS_SUM: return launch_seg<T, GNNOPS_SUM>(src, rowptr, perm, out, nullptr, B, E, K, N, init_from_out, 0, stream);
-        case GNNOPS_MEAN: return launch_seg<T, GNNOPS_SUM>(src, rowptr, perm, out, nullptr, B, E, K, N, init_from_out, 1, stream);
-        case GNNOPS_MUL: return launch_seg<T, GNNOPS_MUL>(src, rowptr, perm, out, nullptr, B, E, K, N, init_from_out, 0, stream);
-        case GNNOPS_MIN: return launch_seg<T, GNNOPS_MIN>(src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, 0, stream);
-        case GNNOPS_MAX: return launch_seg<T, GNNOPS_MAX>(src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, 0, stream);
+        case GNNOPS_SUM: return launch_seg<T, GNNOPS_SUM>(src, rowptr, perm, out, nullptr, B, E, K, N, init_from_out, 0, stream, hw, hb);
+        case GNNOPS_MEAN: return launch_seg<T, GNNOPS_SUM>(src, rowptr, perm, out, nullptr, B, E, K, N, init_from_out, 1, stream, hw, hb);
+        case GNNOPS_MUL: return launch_seg<T, GNNOPS_MUL>(src, rowptr, perm, out, nullptr, B, E, K, N, init_from_out, 0, stream, hw, hb);
+        case GNNOPS_MIN: return launch_seg<T, GNNOPS_MIN>(src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, 0, stream, hw, hb);
+        case GNNOPS_MAX: return launch_seg<T, GNNOPS_MAX>(src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, 0, stream, hw, hb);
     }
     gnnops_set_error("segment_reduce: unknown reduce %d", reduce);
     return GNNOPS_EINVAL;
@@ -331,9 +353,21 @@ int dispatch_reduce(int reduce, const void* src, const int32_t* rowptr, const in
 
 }  // namespace
 
+extern "C" size_t gnnops_hub_workspace_bytes(int64_t E, int64_t K, int reduce) {
+    if (E <= hub::T_HUB || K <= 0) return 0;
+    return hub::layout(E, K, reduce == GNNOPS_MIN || reduce == GNNOPS_MAX).total;
+}
+
 extern "C" int gnnops_segment_reduce(const void* src, const int32_t* rowptr, const int32_t* perm, void* out,
                                      int64_t* arg_out, int64_t B, int64_t E, int64_t K, int64_t N, int dtype,
                                      int reduce, int init_from_out, gnnops_stream_t s) {
+    return gnnops_segment_reduce_hubs(src, rowptr, perm, out, arg_out, B, E, K, N, dtype, reduce, init_from_out, nullptr, 0, s);
+}
+
+extern "C" int gnnops_segment_reduce_hubs(const void* src, const int32_t* rowptr, const int32_t* perm, void* out,
+                                          int64_t* arg_out, int64_t B, int64_t E, int64_t K, int64_t N, int dtype,
+                                          int reduce, int init_from_out, void* hub_workspace, size_t hub_workspace_bytes,
+                                          gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(B >= 0 && E >= 0 && K >= 0 && N >= 0, GNNOPS_EINVAL, "segment_reduce: negative size");
     GNNOPS_REQUIRE(E < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED, "segment_reduce: E must be < 2^31");
@@ -342,9 +376,9 @@ extern "C" int gnnops_segment_reduce(const void* src, const int32_t* rowptr, con
     if (B * N * K == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(rowptr && out && (E == 0 || src), GNNOPS_EINVAL, "segment_reduce: null pointer");
     switch (dtype) {
-        case GNNOPS_F32: return dispatch_reduce<float>(reduce, src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, stream);
-        case GNNOPS_F16: return dispatch_reduce<__half>(reduce, src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, stream);
-        case GNNOPS_BF16: return dispatch_reduce<__hip_bfloat16>(reduce, src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, stream);
+        case GNNOPS_F32: return dispatch_reduce<float>(reduce, src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, stream, hub_workspace, hub_workspace_bytes);
+        case GNNOPS_F16: return dispatch_reduce<__half>(reduce, src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, stream, hub_workspace, hub_workspace_bytes);
+        case GNNOPS_BF16: return dispatch_reduce<__hip_bfloat16>(reduce, src, rowptr, perm, out, arg_out, B, E, K, N, init_from_out, stream, hub_workspace, hub_workspace_bytes);
     }
     gnnops_set_error("segment_reduce: unknown dtype %d", dtype);
     return GNNOPS_EINVAL;

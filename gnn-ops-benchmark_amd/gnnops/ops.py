@@ -264,16 +264,23 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
             # sums / means / products stay on the plan path (one rounding of the fp32 accumulator, whatever the skew).
             ws_bytes = L.gnnops_bucket_workspace_bytes(E, N)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=src.device)
-            rc = L.gnnops_scatter_rows_oneshot(src.data_ptr(), row_index.data_ptr(), out.data_ptr(),
-                                               arg.data_ptr() if want_arg else None, E, K, N, dt, rcode, init,
-                                               ws.data_ptr(), ws_bytes, _stream())
+            rc = L.gnnops_bucket_partition(row_index.data_ptr(), E, N, ws.data_ptr(), ws_bytes, _stream())
+            if rc == _lib.OK:
+                hub_bytes = L.gnnops_hub_workspace_bytes(E, K, rcode)   # heavy destinations are reduced piecewise (hub.h)
+                hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=src.device) if hub_bytes else None
+                rc = L.gnnops_bucket_reduce_hubs(src.data_ptr(), ws.data_ptr(), out.data_ptr(),
+                                                 arg.data_ptr() if want_arg else None, E, K, N, dt, rcode, init,
+                                                 hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream())
             if rc != _lib.EUNSUPPORTED:
                 check(rc, "scatter_rows_oneshot")
                 return (out, arg) if want_arg else out
         if row_index is not None:
             plan = get_plan(row_index, N)
-            rc = L.gnnops_segment_reduce(src.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(), out.data_ptr(),
-                                         arg.data_ptr() if want_arg else None, B, E, K, N, dt, rcode, init, _stream())
+            hub_bytes = L.gnnops_hub_workspace_bytes(E, K, rcode) if B == 1 else 0   # heavy destinations: hub.h
+            hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=src.device) if hub_bytes else None
+            rc = L.gnnops_segment_reduce_hubs(src.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(), out.data_ptr(),
+                                              arg.data_ptr() if want_arg else None, B, E, K, N, dt, rcode, init,
+                                              hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream())
             check(rc, "segment_reduce")
         else:
             full = _broadcast_index(index, src, dim).contiguous()

@@ -88,6 +88,16 @@ int gnnops_segment_reduce(const void* src, const int32_t* rowptr, const int32_t*
                           void* out, int64_t* arg_out,
                           int64_t B, int64_t E, int64_t K, int64_t N,
                           int dtype, int reduce, int init_from_out, gnnops_stream_t stream);
+/* The same with heavy destinations ("hubs": more than 8192 contributions) set aside and reduced piecewise by whole
+ * workgroups instead of serially by one lane group (csrc/hub.h; B == 1, rows of whole 16-B lanes). min / max stay exact;
+ * sums / means / products of a hub are re-associated (deterministic, not bit-identical to the sequential loop).
+ * hub_workspace: gnnops_hub_workspace_bytes(E, K, reduce) bytes, or NULL for the plain form. */
+size_t gnnops_hub_workspace_bytes(int64_t E, int64_t K, int reduce);
+int gnnops_segment_reduce_hubs(const void* src, const int32_t* rowptr, const int32_t* perm,
+                               void* out, int64_t* arg_out,
+                               int64_t B, int64_t E, int64_t K, int64_t N,
+                               int dtype, int reduce, int init_from_out,
+                               void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One-shot row scatter — the same reference call sites as gnnops_segment_reduce (layout R, B == 1), for
@@ -118,6 +128,10 @@ int gnnops_bucket_layout(int64_t E, int64_t N, size_t* keys_offset, size_t* vals
 int gnnops_bucket_reduce(const void* src, const void* workspace, void* out, int64_t* arg_out,
                          int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
                          gnnops_stream_t stream);
+/* gnnops_bucket_reduce with hubs set aside, as gnnops_segment_reduce_hubs (hub_workspace: gnnops_hub_workspace_bytes). */
+int gnnops_bucket_reduce_hubs(const void* src, const void* workspace, void* out, int64_t* arg_out,
+                              int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
+                              void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
 /* torch.index_select(input [N,K], 0, index [E]) -> out [E,K] (benchmark_native_index_select.py:14), push form, from a
  * workspace gnnops_bucket_partition filled for (index, E, N): each selected input row is read once and stored to every
  * output row that selects it. Rows must be a multiple of 16 bytes and 16-B aligned. */

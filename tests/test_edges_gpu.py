@@ -129,7 +129,13 @@ def test_skewed_and_maximal_degree(gnnops, oracle):
     src = torch.rand(70000, 16, generator=g)
     idx = torch.full((70000,), 3, dtype=torch.int64)
     got = gnnops.scatter_add(src.cuda(), idx.cuda(), 0, dim_size=5)
-    assert_bits_equal(got.cpu().numpy(), oracle.scatter(src.numpy(), idx.numpy(), 0, dim_size=5), "all rows -> one destination")
+    exp = oracle.scatter(src.numpy(), idx.numpy(), 0, dim_size=5)
+    # 70 000 contributions to one destination: a hub, reduced piecewise (csrc/hub.h) — deterministic, re-associated
+    np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=2e-5, atol=0)
+    assert torch.equal(got, gnnops.scatter_add(src.cuda(), idx.cuda(), 0, dim_size=5)), "deterministic"
+    few_idx = torch.full((8000,), 3, dtype=torch.int64)               # below the hub threshold: sequential, bit-exact
+    assert_bits_equal(gnnops.scatter_add(src[:8000].cuda(), few_idx.cuda(), 0, dim_size=5).cpu().numpy(),
+                      oracle.scatter(src[:8000].numpy(), few_idx.numpy(), 0, dim_size=5), "8000 rows -> one destination")
     mx, arg = gnnops.scatter_max(src.cuda(), idx.cuda(), 0, dim_size=5)
     emx, earg = oracle.scatter(src.numpy(), idx.numpy(), 0, dim_size=5, reduce="max")
     assert_bits_equal(mx.cpu().numpy(), emx, "max") and assert_bits_equal(arg.cpu().numpy(), earg, "argmax")
