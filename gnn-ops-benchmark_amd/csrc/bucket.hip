@@ -61,7 +61,8 @@ __device__ inline u32x4 load16_coherent(const T* p) {
 // its equal-key lanes; the lowest of them does ONE returning LDS add for the group. The caller must have passed a
 // barrier since the last readers of the LDS arrays; s_perm / s_rowptr are valid after the caller's next barrier.
 __device__ inline uint32_t sort_chunk(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int32_t cbeg, int n,
-                                      int32_t* s_perm, uint32_t* s_whist, int32_t* s_rowptr, uint32_t* s_tmp) {
+                                      int32_t* s_perm, uint32_t* s_whist, int32_t* s_rowptr, uint32_t* s_tmp,
+                                      const uint8_t* s_skip = nullptr) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t* whist = s_whist + wave * 256;
@@ -70,18 +71,31 @@ __device__ inline uint32_t sort_chunk(const uint32_t* __restrict__ keys, const u
     const int rounds_n = (n + THREADS - 1) / THREADS;   // rows of 64 per wave
     const int wave_base = wave * rounds_n * 64;
     uint32_t dg[ROUNDS], vv[ROUNDS], rk[ROUNDS];
-    uint32_t is_leader = 0;
+    uint32_t is_leader = 0, valid_bits = 0;
+    // s_skip (destinations set aside as hubs, hub.h): their entries take no part — and a window made of nothing else
+    // (most windows of a hub's bucket) costs one read of its keys instead of a full ranking pass
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         dg[r] = 0; vv[r] = 0; rk[r] = 0;
         if (r < rounds_n) {
             const int i = wave_base + r * 64 + lane;
-            const bool valid = i < n;
-            if (valid) {
+            if (i < n) {
                 dg[r] = keys[cbeg + i] & (BROWS - 1);
                 vv[r] = vals[cbeg + i];
+                if (!(s_skip && s_skip[dg[r]])) valid_bits |= 1u << r;
             }
-            const uint32_t d = dg[r];
+        }
+    }
+    if (s_skip && !__syncthreads_or(valid_bits != 0u)) {  // uniform: nothing of this window is ours
+        s_rowptr[tid] = 0;
+        if (tid == BROWS - 1) s_rowptr[BROWS] = 0;
+        return 0;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r < rounds_n) {
+            const bool valid = (valid_bits >> r) & 1u;
+            const uint32_t d = valid ? dg[r] : 0u;
             const uint64_t vb = __ballot(valid);
             uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
 #pragma unroll
@@ -128,8 +142,7 @@ __device__ inline uint32_t sort_chunk(const uint32_t* __restrict__ keys, const u
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         if (r < rounds_n) {
-            const int i = wave_base + r * 64 + lane;
-            if (i < n) s_perm[whist[dg[r]] + rk[r]] = (int32_t)vv[r];
+            if ((valid_bits >> r) & 1u) s_perm[whist[dg[r]] + rk[r]] = (int32_t)vv[r];
         }
     }
     return tot;
@@ -164,7 +177,25 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
         if (hub_on && bend - bbeg > hub::T_HUB) {  // only such a bucket can hold a hub: count per destination first
             s_deg[tid] = 0;
             __syncthreads();
-            for (int32_t i = bbeg + tid; i < bend; i += THREADS) atomicAdd(&s_deg[keys[i] & (BROWS - 1)], 1u);
+            // counted per wave: eight ballots give every lane its equal-key lanes and the lowest of them adds the group size —
+            // a hub's bucket is mostly ONE key, and 10^6 same-address LDS atomics would take milliseconds
+            for (int32_t i0 = bbeg + (tid & ~63); i0 < bend; i0 += THREADS) {
+                const int32_t i = i0 + (tid & 63);
+                const bool valid = i < bend;
+                const uint32_t d = valid ? (keys[i] & (BROWS - 1)) : 0u;
+                const uint64_t vb = __ballot(valid);
+                uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+                    const uint64_t bal = __ballot(xb != 0u);
+                    m_lo &= ~((uint32_t)bal ^ xb);
+                    m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
+                }
+                const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
+                const uint64_t below = (tid & 63) ? (m & (~0ull >> (64 - (tid & 63)))) : 0ull;
+                if (valid && below == 0) atomicAdd(&s_deg[d], (uint32_t)__popcll(m));
+            }
             __syncthreads();
             const uint32_t is_hub = s_deg[tid] > (uint32_t)hub::T_HUB ? 1u : 0u;
             const uint32_t rank = block_excl_scan_u32<WAVES>(is_hub, s_tmp, nullptr);  // the smallest ids first: deterministic
@@ -180,7 +211,7 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
             __syncthreads();  // previous chunk's / bucket's readers are done with s_perm, s_rowptr, s_cnt
             if (first) s_cnt[tid] = 0;
 
-            const uint32_t tot = sort_chunk(keys, vals, cbeg, n, s_perm, s_whist, s_rowptr, s_tmp);
+            const uint32_t tot = sort_chunk(keys, vals, cbeg, n, s_perm, s_whist, s_rowptr, s_tmp, hub_on ? s_hub : nullptr);
             s_cnt[tid] += tot;
             __syncthreads();
 
