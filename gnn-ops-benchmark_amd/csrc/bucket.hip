@@ -61,8 +61,7 @@ __device__ inline u32x4 load16_coherent(const T* p) {
 // its equal-key lanes; the lowest of them does ONE returning LDS add for the group. The caller must have passed a
 // barrier since the last readers of the LDS arrays; s_perm / s_rowptr are valid after the caller's next barrier.
 __device__ inline uint32_t sort_chunk(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int32_t cbeg, int n,
-                                      int32_t* s_perm, uint32_t* s_whist, int32_t* s_rowptr, uint32_t* s_tmp,
-                                      const uint8_t* s_skip = nullptr) {
+                                      int32_t* s_perm, uint32_t* s_whist, int32_t* s_rowptr, uint32_t* s_tmp) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t* whist = s_whist + wave * 256;
@@ -71,31 +70,18 @@ __device__ inline uint32_t sort_chunk(const uint32_t* __restrict__ keys, const u
     const int rounds_n = (n + THREADS - 1) / THREADS;   // rows of 64 per wave
     const int wave_base = wave * rounds_n * 64;
     uint32_t dg[ROUNDS], vv[ROUNDS], rk[ROUNDS];
-    uint32_t is_leader = 0, valid_bits = 0;
-    // s_skip (destinations set aside as hubs, hub.h): their entries take no part — and a window made of nothing else
-    // (most windows of a hub's bucket) costs one read of its keys instead of a full ranking pass
+    uint32_t is_leader = 0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         dg[r] = 0; vv[r] = 0; rk[r] = 0;
         if (r < rounds_n) {
             const int i = wave_base + r * 64 + lane;
-            if (i < n) {
+            const bool valid = i < n;
+            if (valid) {
                 dg[r] = keys[cbeg + i] & (BROWS - 1);
                 vv[r] = vals[cbeg + i];
-                if (!(s_skip && s_skip[dg[r]])) valid_bits |= 1u << r;
             }
-        }
-    }
-    if (s_skip && !__syncthreads_or(valid_bits != 0u)) {  // uniform: nothing of this window is ours
-        s_rowptr[tid] = 0;
-        if (tid == BROWS - 1) s_rowptr[BROWS] = 0;
-        return 0;
-    }
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        if (r < rounds_n) {
-            const bool valid = (valid_bits >> r) & 1u;
-            const uint32_t d = valid ? dg[r] : 0u;
+            const uint32_t d = dg[r];
             const uint64_t vb = __ballot(valid);
             uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
 #pragma unroll
@@ -142,10 +128,77 @@ __device__ inline uint32_t sort_chunk(const uint32_t* __restrict__ keys, const u
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         if (r < rounds_n) {
-            if ((valid_bits >> r) & 1u) s_perm[whist[dg[r]] + rk[r]] = (int32_t)vv[r];
+            const int i = wave_base + r * 64 + lane;
+            if (i < n) s_perm[whist[dg[r]] + rk[r]] = (int32_t)vv[r];
         }
     }
     return tot;
+}
+
+// Hub detection for a large bucket (cold path, kept out of line so that its registers do not add to the row walk's):
+// counts the bucket's contributions per destination, sets aside up to MAX_PER_BUCKET hubs (hub.h) and, if there are any,
+// compacts the bucket's OTHER entries — a handful scattered among the hubs' — stably into the spare half of the
+// partition's ping-pong buffers at the bucket's own offset. Returns the end of that compacted list, or -1 (no hub).
+__device__ __noinline__ int32_t hub_prepare(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int32_t bbeg,
+                                            int32_t bend, int64_t bucket, int64_t N, hub::Ws hw,
+                                            uint32_t* __restrict__ spare_keys, uint32_t* __restrict__ spare_vals,
+                                            uint32_t* s_deg, uint8_t* s_hub, uint32_t* s_tmp) {
+    const int tid = threadIdx.x;
+    s_deg[tid] = 0;
+    __syncthreads();
+    // counted per wave: eight ballots give every lane its equal-key lanes and the lowest of them adds the group size —
+    // a hub's bucket is mostly ONE key, and 10^6 same-address LDS atomics would take milliseconds
+    for (int32_t i0 = bbeg + (tid & ~63); i0 < bend; i0 += THREADS) {
+        const int32_t i = i0 + (tid & 63);
+        const bool valid = i < bend;
+        const uint32_t d = valid ? (keys[i] & (BROWS - 1)) : 0u;
+        const uint64_t vb = __ballot(valid);
+        uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+            const uint64_t bal = __ballot(xb != 0u);
+            m_lo &= ~((uint32_t)bal ^ xb);
+            m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
+        }
+        const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
+        const uint64_t below = (tid & 63) ? (m & (~0ull >> (64 - (tid & 63)))) : 0ull;
+        if (valid && below == 0) atomicAdd(&s_deg[d], (uint32_t)__popcll(m));
+    }
+    __syncthreads();
+    const uint32_t is_hub = s_deg[tid] > (uint32_t)hub::T_HUB ? 1u : 0u;
+    const uint32_t rank = block_excl_scan_u32<WAVES>(is_hub, s_tmp, nullptr);  // the smallest ids first: deterministic
+    const bool aside = is_hub && rank < (uint32_t)hub::MAX_PER_BUCKET && bucket * BROWS + tid < N;
+    if (aside) {
+        s_hub[tid] = 1;
+        hub::append(hw, (int)(bucket * BROWS + tid), bbeg, bend, (int)s_deg[tid]);
+    }
+    if (__syncthreads_count(aside) == 0) return -1;
+    constexpr int IPT = 8;
+    uint32_t running = 0;
+    for (int32_t w0 = bbeg; w0 < bend; w0 += THREADS * IPT) {
+        uint32_t kk[IPT], vv2[IPT];
+        uint32_t c = 0, keep = 0;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int32_t i = w0 + tid * IPT + j;
+            kk[j] = 0; vv2[j] = 0;
+            if (i < bend) {
+                kk[j] = keys[i];
+                vv2[j] = vals[i];
+                if (!s_hub[kk[j] & (BROWS - 1)]) { keep |= 1u << j; ++c; }
+            }
+        }
+        uint32_t tot;
+        uint32_t off = bbeg + running + block_excl_scan_u32<WAVES>(c, s_tmp, &tot);
+#pragma unroll
+        for (int j = 0; j < IPT; ++j)
+            if ((keep >> j) & 1u) { spare_keys[off] = kk[j]; spare_vals[off] = vv2[j]; ++off; }
+        running += tot;
+    }
+    __threadfence();
+    __syncthreads();
+    return bbeg + (int32_t)running;
 }
 
 template <typename T, int R>
@@ -154,7 +207,9 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
                                                                 const int32_t* __restrict__ bptr, T* __restrict__ out,
                                                                 int64_t* __restrict__ arg_out, int64_t E, int64_t K,
                                                                 int64_t N, int64_t NB, int gshift, int kchunks,
-                                                                int init_from_out, int is_mean, hub::Ws hw, int hub_on) {
+                                                                int init_from_out, int is_mean, hub::Ws hw, int hub_on,
+                                                                uint32_t* __restrict__ spare_keys,
+                                                                uint32_t* __restrict__ spare_vals) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
     __shared__ uint32_t s_deg[BROWS];  // hub detection: contributions per destination of a large bucket
@@ -172,46 +227,27 @@ __global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restr
 
     for (int64_t bucket = blockIdx.x; bucket < NB; bucket += gridDim.x) {
         const int32_t bbeg = bptr[bucket], bend = bptr[bucket + 1];
+        const uint32_t* wkeys = keys;   // what the windows below walk: the bucket, or its non-hub entries compacted
+        const uint32_t* wvals = vals;
+        int32_t wend = bend;
         __syncthreads();  // the previous bucket's readers are done with s_hub
         s_hub[tid] = 0;
-        if (hub_on && bend - bbeg > hub::T_HUB) {  // only such a bucket can hold a hub: count per destination first
-            s_deg[tid] = 0;
-            __syncthreads();
-            // counted per wave: eight ballots give every lane its equal-key lanes and the lowest of them adds the group size —
-            // a hub's bucket is mostly ONE key, and 10^6 same-address LDS atomics would take milliseconds
-            for (int32_t i0 = bbeg + (tid & ~63); i0 < bend; i0 += THREADS) {
-                const int32_t i = i0 + (tid & 63);
-                const bool valid = i < bend;
-                const uint32_t d = valid ? (keys[i] & (BROWS - 1)) : 0u;
-                const uint64_t vb = __ballot(valid);
-                uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
-                    const uint64_t bal = __ballot(xb != 0u);
-                    m_lo &= ~((uint32_t)bal ^ xb);
-                    m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
-                }
-                const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
-                const uint64_t below = (tid & 63) ? (m & (~0ull >> (64 - (tid & 63)))) : 0ull;
-                if (valid && below == 0) atomicAdd(&s_deg[d], (uint32_t)__popcll(m));
-            }
-            __syncthreads();
-            const uint32_t is_hub = s_deg[tid] > (uint32_t)hub::T_HUB ? 1u : 0u;
-            const uint32_t rank = block_excl_scan_u32<WAVES>(is_hub, s_tmp, nullptr);  // the smallest ids first: deterministic
-            if (is_hub && rank < (uint32_t)hub::MAX_PER_BUCKET && bucket * BROWS + tid < N) {
-                s_hub[tid] = 1;
-                hub::append(hw, (int)(bucket * BROWS + tid), bbeg, bend, (int)s_deg[tid]);
+        if (hub_on && bend - bbeg > hub::T_HUB) {  // only such a bucket can hold a hub
+            const int32_t ce = hub_prepare(keys, vals, bbeg, bend, bucket, N, hw, spare_keys, spare_vals, s_deg, s_hub, s_tmp);
+            if (ce >= 0) {
+                wkeys = spare_keys;
+                wvals = spare_vals;
+                wend = ce;
             }
         }
         for (int32_t cbeg = bbeg;; cbeg += CAP) {
             const bool first = cbeg == bbeg;
-            const bool last = cbeg + CAP >= bend;
-            const int n = (bend - cbeg < CAP) ? (bend - cbeg) : CAP;
+            const bool last = cbeg + CAP >= wend;
+            const int n = (wend - cbeg < CAP) ? (wend - cbeg) : CAP;
             __syncthreads();  // previous chunk's / bucket's readers are done with s_perm, s_rowptr, s_cnt
             if (first) s_cnt[tid] = 0;
 
-            const uint32_t tot = sort_chunk(keys, vals, cbeg, n, s_perm, s_whist, s_rowptr, s_tmp, hub_on ? s_hub : nullptr);
+            const uint32_t tot = sort_chunk(wkeys, wvals, cbeg, n, s_perm, s_whist, s_rowptr, s_tmp);
             s_cnt[tid] += tot;
             __syncthreads();
 
@@ -355,7 +391,7 @@ __global__ __launch_bounds__(THREADS) void bucket_push_kernel(const char* __rest
 template <typename T, int R>
 int launch_bucket(const void* src, const uint32_t* keys, const uint32_t* vals, const int32_t* bptr, void* out,
                   int64_t* arg_out, int64_t E, int64_t K, int64_t N, int64_t NB, int init_from_out, int is_mean,
-                  hipStream_t stream, void* hub_ws, size_t hub_ws_bytes) {
+                  hipStream_t stream, void* hub_ws, size_t hub_ws_bytes, uint32_t* spare_keys, uint32_t* spare_vals) {
     constexpr int VEC = Elem<T>::VEC;
     const int64_t vecs = K / VEC;
     int gshift = 0;
@@ -374,7 +410,8 @@ int launch_bucket(const void* src, const uint32_t* keys, const uint32_t* vals, c
         }
     }
     hipLaunchKernelGGL((bucket_reduce_kernel<T, R>), dim3(grid), dim3(THREADS), 0, stream, (const T*)src, keys, vals, bptr,
-                       (T*)out, arg_out, E, K, N, NB, gshift, kchunks, init_from_out, is_mean, hw, hub_on);
+                       (T*)out, arg_out, E, K, N, NB, gshift, kchunks, init_from_out, is_mean, hw, hub_on, spare_keys,
+                       spare_vals);
     if (hub_on)
         hub::launch_pass<T, R, true>((const T*)src, nullptr, keys, vals, (T*)out, arg_out, hw, E, K, gshift, kchunks,
                                      init_from_out, is_mean, stream);
@@ -384,13 +421,13 @@ int launch_bucket(const void* src, const uint32_t* keys, const uint32_t* vals, c
 template <typename T>
 int dispatch_bucket(int reduce, const void* src, const uint32_t* keys, const uint32_t* vals, const int32_t* bptr, void* out,
                     int64_t* arg_out, int64_t E, int64_t K, int64_t N, int64_t NB, int init_from_out, hipStream_t stream,
-                    void* hw = nullptr, size_t hb = 0) {
+                    void* hw = nullptr, size_t hb = 0, uint32_t* sk = nullptr, uint32_t* sv = nullptr) {
     switch (reduce) {
-        case GNNOPS_SUM: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream, hw, hb);
-        case GNNOPS_MEAN: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 1, stream, hw, hb);
-        case GNNOPS_MUL: return launch_bucket<T, GNNOPS_MUL>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream, hw, hb);
-        case GNNOPS_MIN: return launch_bucket<T, GNNOPS_MIN>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream, hw, hb);
-        case GNNOPS_MAX: return launch_bucket<T, GNNOPS_MAX>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream, hw, hb);
+        case GNNOPS_SUM: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream, hw, hb, sk, sv);
+        case GNNOPS_MEAN: return launch_bucket<T, GNNOPS_SUM>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 1, stream, hw, hb, sk, sv);
+        case GNNOPS_MUL: return launch_bucket<T, GNNOPS_MUL>(src, keys, vals, bptr, out, nullptr, E, K, N, NB, init_from_out, 0, stream, hw, hb, sk, sv);
+        case GNNOPS_MIN: return launch_bucket<T, GNNOPS_MIN>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream, hw, hb, sk, sv);
+        case GNNOPS_MAX: return launch_bucket<T, GNNOPS_MAX>(src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, 0, stream, hw, hb, sk, sv);
     }
     gnnops_set_error("scatter_rows_oneshot: unknown reduce %d", reduce);
     return GNNOPS_EINVAL;
@@ -541,10 +578,13 @@ extern "C" int gnnops_bucket_reduce_hubs(const void* src, const void* workspace,
     const uint32_t* vals = (const uint32_t*)(w + (last ? l.vals_b : l.vals_a));
     const int32_t* bptr = (const int32_t*)(w + l.bptr);
     const int64_t NB = gnnops_cdiv(N, BROWS);
+    // the other half of the ping-pong buffers is scratch once the partition is built: the hub path compacts into it
+    uint32_t* sk = (uint32_t*)(const_cast<char*>(w) + (last ? l.keys_a : l.keys_b));
+    uint32_t* sv = (uint32_t*)(const_cast<char*>(w) + (last ? l.vals_a : l.vals_b));
     switch (dtype) {
-        case GNNOPS_F32: return dispatch_bucket<float>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes);
-        case GNNOPS_F16: return dispatch_bucket<__half>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes);
-        default: return dispatch_bucket<__hip_bfloat16>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes);
+        case GNNOPS_F32: return dispatch_bucket<float>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes, sk, sv);
+        case GNNOPS_F16: return dispatch_bucket<__half>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes, sk, sv);
+        default: return dispatch_bucket<__hip_bfloat16>(reduce, src, keys, vals, bptr, out, arg_out, E, K, N, NB, init_from_out, stream, hub_workspace, hub_workspace_bytes, sk, sv);
     }
 }
 
