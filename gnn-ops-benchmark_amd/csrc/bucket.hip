@@ -349,7 +349,11 @@ __global__ __launch_bounds__(THREADS) void bucket_push_kernel(const char* __rest
                                                               const uint32_t* __restrict__ vals,
                                                               const int32_t* __restrict__ bptr, char* __restrict__ out,
                                                               int64_t N, int64_t NB, int64_t rowbytes, int gshift,
-                                                              int chunks) {
+                                                              int chunks, hub::Ws hw, int hub_on,
+                                                              uint32_t* __restrict__ spare_keys,
+                                                              uint32_t* __restrict__ spare_vals) {
+    __shared__ uint32_t s_deg[BROWS];
+    __shared__ uint8_t s_hub[BROWS];   // 1: a hot row, its outputs are written by the hub pass (hub.h)
     __shared__ int32_t s_perm[CAP];
     __shared__ uint32_t s_whist[WAVES * 256];
     __shared__ int32_t s_rowptr[BROWS + 1];
@@ -360,17 +364,30 @@ __global__ __launch_bounds__(THREADS) void bucket_push_kernel(const char* __rest
     const int gi = tid >> gshift, groups = THREADS >> gshift;
     for (int64_t bucket = blockIdx.x; bucket < NB; bucket += gridDim.x) {
         const int32_t bbeg = bptr[bucket], bend = bptr[bucket + 1];
-        for (int32_t cbeg = bbeg; cbeg < bend; cbeg += CAP) {   // an unselected bucket stores nothing
-            const int n = (bend - cbeg < CAP) ? (bend - cbeg) : CAP;
+        const uint32_t* wkeys = keys;
+        const uint32_t* wvals = vals;
+        int32_t wend = bend;
+        __syncthreads();
+        s_hub[tid] = 0;
+        if (hub_on && bend - bbeg > hub::T_HUB) {
+            const int32_t ce = hub_prepare(keys, vals, bbeg, bend, bucket, N, hw, spare_keys, spare_vals, s_deg, s_hub, s_tmp);
+            if (ce >= 0) {
+                wkeys = spare_keys;
+                wvals = spare_vals;
+                wend = ce;
+            }
+        }
+        for (int32_t cbeg = bbeg; cbeg < wend; cbeg += CAP) {   // an unselected bucket stores nothing
+            const int n = (wend - cbeg < CAP) ? (wend - cbeg) : CAP;
             __syncthreads();
-            sort_chunk(keys, vals, cbeg, n, s_perm, s_whist, s_rowptr, s_tmp);
+            sort_chunk(wkeys, wvals, cbeg, n, s_perm, s_whist, s_rowptr, s_tmp);
             __syncthreads();
             for (int item = gi; item < BROWS * chunks; item += groups) {
                 const int dloc = item & (BROWS - 1);
                 const int c = item >> BSHIFT;
                 const int64_t nrow = bucket * BROWS + dloc;
                 const int64_t colb = ((int64_t)c * G + gl) * 16;
-                if (nrow >= N || colb >= rowbytes) continue;
+                if (nrow >= N || colb >= rowbytes || s_hub[dloc]) continue;
                 const int32_t beg = s_rowptr[dloc], end = s_rowptr[dloc + 1];
                 if (beg == end) continue;
                 const u32x4 v = load16<true>(in + nrow * rowbytes + colb);
@@ -592,6 +609,13 @@ extern "C" int gnnops_bucket_reduce_hubs(const void* src, const void* workspace,
 // every selected input row is read once. Rows are K * elem_bytes bytes, a multiple of 16, 16-B aligned.
 extern "C" int gnnops_bucket_select(const void* input, const void* workspace, void* out, int64_t N, int64_t K, int64_t E,
                                     int elem_bytes, gnnops_stream_t s) {
+    return gnnops_bucket_select_hubs(input, workspace, out, N, K, E, elem_bytes, nullptr, 0, s);
+}
+
+// The same with hot rows (selected by more than 8192 outputs) set aside and written by whole workgroups (hub.h);
+// hub_workspace: gnnops_hub_workspace_bytes(E, 0, 0) bytes, or NULL.
+extern "C" int gnnops_bucket_select_hubs(const void* input, const void* workspace, void* out, int64_t N, int64_t K, int64_t E,
+                                         int elem_bytes, void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "bucket_select: negative size");
     const int64_t rowbytes = K * elem_bytes;
@@ -612,8 +636,22 @@ extern "C" int gnnops_bucket_select(const void* input, const void* workspace, vo
     while ((1 << gshift) < lanes && gshift < 6) ++gshift;
     const int chunks = (int)gnnops_cdiv(lanes, (int64_t)1 << gshift);
     const int grid = gnnops_grid_cap(NB, 256 * 16);
+    hub::Ws hw{};
+    int hub_on = 0;
+    if (hub_workspace && E > hub::T_HUB) {
+        const hub::Layout hl = hub::layout(E, 0, false);
+        if (hub_workspace_bytes >= hl.total) {
+            hw = hub::make_ws(hub_workspace, hl, E, false);
+            if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+            hub_on = 1;
+        }
+    }
+    uint32_t* sk = (uint32_t*)(const_cast<char*>(w) + (last ? l.keys_a : l.keys_b));   // spare half of the ping-pong buffers
+    uint32_t* sv = (uint32_t*)(const_cast<char*>(w) + (last ? l.vals_a : l.vals_b));
     hipLaunchKernelGGL((bucket_push_kernel<8>), dim3(grid), dim3(THREADS), 0, stream, (const char*)input, keys, vals, bptr,
-                       (char*)out, N, NB, rowbytes, gshift, chunks);
+                       (char*)out, N, NB, rowbytes, gshift, chunks, hw, hub_on, sk, sv);
+    if (hub_on)
+        hub::launch_push_pass(true, (const char*)input, nullptr, keys, vals, (char*)out, hw, rowbytes, gshift, chunks, stream);
     return gnnops_check_launch("bucket_select");
 }
 

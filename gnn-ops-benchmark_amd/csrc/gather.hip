@@ -5,6 +5,7 @@
 // All HBM-bound byte movers: 16-B lane accesses along the feature dimension, several rows in flight
 // per lane group to cover the dependent index -> row latency. No MFMA here by design.
 #include "common.h"
+#include "hub.h"
 #include <type_traits>
 
 namespace {
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void select_rows_push_kernel(const char* __res
                                                                const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ perm, char* __restrict__ out,
                                                                int64_t B, int64_t N, int64_t E, int64_t rowbytes,
-                                                               int gshift, int chunks) {
+                                                               int gshift, int chunks, hub::Ws hw, int hub_on) {
     const int G = 1 << gshift;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(256) void select_rows_push_kernel(const char* __res
         if (colb >= rowbytes) continue;
         const int32_t beg = rowptr[n], end = rowptr[n + 1];
         if (beg == end) continue;
+        if (hub_on && end - beg > hub::T_HUB) {  // a hot row (hub.h): its outputs are written by the hub pass
+            if (gl == 0 && c == 0) hub::append(hw, (int)n, beg, end, end - beg);
+            continue;
+        }
         const u32x4 v = load16<NT_LD>(in + (b * N + n) * rowbytes + colb);
         char* outb = out + (b * E) * rowbytes + colb;
         for (int32_t j = beg; j < end; j += PU) {
@@ -631,6 +636,14 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
 extern "C" int gnnops_index_select_planned(const void* input, const int32_t* rowptr, const int32_t* perm, void* out,
                                            int64_t B, int64_t N, int64_t K, int64_t E, int elem_bytes,
                                            gnnops_stream_t s) {
+    return gnnops_index_select_planned_hubs(input, rowptr, perm, out, B, N, K, E, elem_bytes, nullptr, 0, s);
+}
+
+// The same with hot rows (selected by more than 8192 outputs) set aside and written by whole workgroups (hub.h);
+// hub_workspace: gnnops_hub_workspace_bytes(E, 0, 0) bytes, or NULL.
+extern "C" int gnnops_index_select_planned_hubs(const void* input, const int32_t* rowptr, const int32_t* perm, void* out,
+                                                int64_t B, int64_t N, int64_t K, int64_t E, int elem_bytes,
+                                                void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "index_select_planned: negative size");
     GNNOPS_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, GNNOPS_EUNSUPPORTED,
@@ -643,8 +656,21 @@ extern "C" int gnnops_index_select_planned(const void* input, const int32_t* row
     RowGeom g = row_geom(rowbytes / 16);
     const int64_t items = B * g.chunks * N;
     const int grid = gnnops_grid_cap(gnnops_cdiv(items, 256 >> g.gshift), 256 * 64);
+    hub::Ws hw{};
+    int hub_on = 0;
+    if (hub_workspace && B == 1 && E > hub::T_HUB) {
+        const hub::Layout hl = hub::layout(E, 0, false);
+        if (hub_workspace_bytes >= hl.total) {
+            hw = hub::make_ws(hub_workspace, hl, E, false);
+            if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+            hub_on = 1;
+        }
+    }
     hipLaunchKernelGGL((select_rows_push_kernel<true, true, 8>), dim3(grid), dim3(256), 0, stream, (const char*)input,
-                       rowptr, perm, (char*)out, B, N, E, rowbytes, g.gshift, g.chunks);
+                       rowptr, perm, (char*)out, B, N, E, rowbytes, g.gshift, g.chunks, hw, hub_on);
+    if (hub_on)
+        hub::launch_push_pass(false, (const char*)input, perm, nullptr, nullptr, (char*)out, hw, rowbytes, g.gshift, g.chunks,
+                              stream);
     return gnnops_check_launch("index_select_planned");
 }
 

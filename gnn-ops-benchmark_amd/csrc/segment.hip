@@ -354,7 +354,7 @@ int dispatch_reduce(int reduce, const void* src, const int32_t* rowptr, const in
 }  // namespace
 
 extern "C" size_t gnnops_hub_workspace_bytes(int64_t E, int64_t K, int reduce) {
-    if (E <= hub::T_HUB || K <= 0) return 0;
+    if (E <= hub::T_HUB || K < 0) return 0;  // K == 0: the lists only (push-form index_select)
     return hub::layout(E, K, reduce == GNNOPS_MIN || reduce == GNNOPS_MAX).total;
 }
 

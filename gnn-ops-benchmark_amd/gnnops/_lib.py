@@ -31,6 +31,8 @@ SIGNATURES = {
     "gnnops_bucket_reduce_hubs": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
     "gnnops_hub_workspace_bytes": (_sz, [_i64, _i64, _ci]),
     "gnnops_segment_reduce_hubs": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
+    "gnnops_bucket_select_hubs": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
+    "gnnops_index_select_planned_hubs": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
     "gnnops_bucket_select": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp]),
     "gnnops_scatter_rows_oneshot": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
     "gnnops_scatter_elementwise_workspace_bytes": (_sz, [_i64, _i64, _i64, _ci, _ci]),

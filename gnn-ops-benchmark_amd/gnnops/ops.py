@@ -395,7 +395,10 @@ def index_select(input, dim, index, plan=None):
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
             with torch.cuda.device(input.device):
                 check(L.gnnops_bucket_partition(index.data_ptr(), E, N, ws.data_ptr(), ws_bytes, _stream()), "bucket_partition")
-                check(L.gnnops_bucket_select(input.data_ptr(), ws.data_ptr(), out.data_ptr(), N, K, E, eb, _stream()),
+                hub_bytes = L.gnnops_hub_workspace_bytes(E, 0, 0)   # hot rows are written by whole workgroups (hub.h)
+                hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=input.device) if hub_bytes else None
+                check(L.gnnops_bucket_select_hubs(input.data_ptr(), ws.data_ptr(), out.data_ptr(), N, K, E, eb,
+                                                  hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream()),
                       "bucket_select")
             return out
         plan = get_plan(index, N)
@@ -403,8 +406,11 @@ def index_select(input, dim, index, plan=None):
         if plan is not None:
             if plan.E != E or plan.N != N:
                 raise ValueError("index_select: plan does not match index / input.size(dim)")
-            rc = L.gnnops_index_select_planned(input.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(),
-                                               out.data_ptr(), B, N, K, E, eb, _stream())
+            hub_bytes = L.gnnops_hub_workspace_bytes(E, 0, 0) if B == 1 else 0   # hot rows: hub.h
+            hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=input.device) if hub_bytes else None
+            rc = L.gnnops_index_select_planned_hubs(input.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(),
+                                                    out.data_ptr(), B, N, K, E, eb,
+                                                    hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream())
         else:
             rc = L.gnnops_index_select(input.data_ptr(), index.data_ptr(), out.data_ptr(), B, N, K, E, eb, _stream())
     check(rc, "index_select")

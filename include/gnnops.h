@@ -137,6 +137,13 @@ int gnnops_bucket_reduce_hubs(const void* src, const void* workspace, void* out,
  * output row that selects it. Rows must be a multiple of 16 bytes and 16-B aligned. */
 int gnnops_bucket_select(const void* input, const void* workspace, void* out, int64_t N, int64_t K, int64_t E,
                          int elem_bytes, gnnops_stream_t stream);
+/* Push-form index_select with hot rows (selected by more than 8192 outputs) set aside and written by whole workgroups
+ * instead of one lane group (csrc/hub.h): hub_workspace = gnnops_hub_workspace_bytes(E, 0, 0) bytes, or NULL. */
+int gnnops_bucket_select_hubs(const void* input, const void* workspace, void* out, int64_t N, int64_t K, int64_t E,
+                              int elem_bytes, void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
+int gnnops_index_select_planned_hubs(const void* input, const int32_t* rowptr, const int32_t* perm, void* out,
+                                     int64_t B, int64_t N, int64_t K, int64_t E, int elem_bytes,
+                                     void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Element-wise scatter, layout F (index has the shape of src) — what the reference scripts build

@@ -146,8 +146,10 @@ def _bucket_select(gnnops, table, idx):
     ws_bytes = L.gnnops_bucket_workspace_bytes(E, N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
     _lib.check(L.gnnops_bucket_partition(idx.data_ptr(), E, N, ws.data_ptr(), ws_bytes, _stream()), "bucket_partition")
-    _lib.check(L.gnnops_bucket_select(table.data_ptr(), ws.data_ptr(), out.data_ptr(), N, K, E, table.element_size(),
-                                      _stream()), "bucket_select")
+    hb = L.gnnops_hub_workspace_bytes(E, 0, 0)
+    hw = torch.empty(max(hb, 1), dtype=torch.uint8, device=table.device)
+    _lib.check(L.gnnops_bucket_select_hubs(table.data_ptr(), ws.data_ptr(), out.data_ptr(), N, K, E, table.element_size(),
+                                           hw.data_ptr() if hb else None, hb, _stream()), "bucket_select")
     return out
 
 
@@ -216,3 +218,21 @@ def test_hubs_are_reduced_piecewise(gnnops, oracle, reduce, cache):
         go = got_out.cpu().numpy()
         assert np.array_equal(go[~hubs], eo[~hubs])
         np.testing.assert_allclose(go[hubs], eo[hubs], rtol=3e-4, atol=3e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_index_select_hot_rows(gnnops, dt):
+    """Push-form index_select with hot table rows (selected by more than 8192 outputs — hub.h): two in one bucket of 256
+    rows, one elsewhere, plus ordinary rows; bucketed (one-shot) and planned forms both equal torch's gather."""
+    N, K, E = 3000, 64, 300_000
+    g = torch.Generator().manual_seed(31)
+    table = (torch.rand(N, K, generator=g) * 100).to(dt).cuda()
+    idx = torch.randint(0, N, (E,), generator=g)
+    r = torch.rand(E, generator=g)
+    idx[r < 0.3] = 5
+    idx[(r >= 0.3) & (r < 0.35)] = 9
+    idx[(r >= 0.35) & (r < 0.4)] = 2000
+    idx = idx.cuda()
+    exp = table[idx]
+    assert torch.equal(_bucket_select(gnnops, table, idx), exp)
+    assert torch.equal(gnnops.index_select(table, 0, idx, plan=gnnops.Plan(idx, N)), exp)
