@@ -264,6 +264,93 @@ __global__ __launch_bounds__(THREADS) void hub_combine_kernel(T* __restrict__ ou
     }
 }
 
+// SpMM (spmm.hip): an output row with more than T_HUB nonzeros. Same pieces; a contribution is value[e] * mat[col[e], :]
+// (two roundings, as in spmm_rows_kernel), the piece partials are folded by hub_combine_kernel<T, GNNOPS_SUM>.
+template <typename T>
+__global__ __launch_bounds__(THREADS) void hub_partial_spmm_kernel(const int32_t* __restrict__ perm,
+                                                                   const int64_t* __restrict__ col, const T* __restrict__ value,
+                                                                   const T* __restrict__ mat, Ws w, int64_t D, int gshift,
+                                                                   int kchunks) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ int32_t s_match[PART];
+    __shared__ float s_part[THREADS * VEC];
+    const int tid = threadIdx.x;
+    const int G = 1 << gshift, gl = tid & (G - 1), gi = tid >> gshift, groups = THREADS >> gshift;
+    int npieces = w.counters[1];
+    if (npieces > w.cap_p) npieces = w.cap_p;
+    for (int q = blockIdx.x; q < npieces; q += gridDim.x) {
+        const int h = w.pieces[2 * q];
+        if (h < 0) continue;
+        const int pno = w.pieces[2 * q + 1];
+        const int beg = w.hubs[4 * h + 1], end = w.hubs[4 * h + 2];
+        const int pb = beg + pno * PART;
+        const int n = (end - pb < PART) ? end - pb : PART;
+        __syncthreads();
+        for (int i = tid; i < n; i += THREADS) s_match[i] = perm ? perm[pb + i] : pb + i;
+        __syncthreads();
+        const int part = (n + groups - 1) / groups;
+        const int jb = gi * part, je = (jb + part < n) ? jb + part : n;
+        for (int chunk = 0; chunk < kchunks; ++chunk) {
+            const int64_t c0 = ((int64_t)chunk * G + gl) * VEC;
+            float acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+            if (c0 < D) {
+                for (int j = jb; j < je; j += U) {
+                    int64_t c[U];
+                    float wt[U];
+                    u32x4 rows[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        c[u] = -1;
+                        if (j + u < je) {
+                            const int32_t e = s_match[j + u];
+                            c[u] = col[e];
+                            wt[u] = value ? Elem<T>::load(value + e) : 1.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (c[u] >= 0) rows[u] = load16<false>(mat + c[u] * D + c0);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (c[u] >= 0) {
+                            float f[VEC];
+                            Elem<T>::unpack(rows[u], f);
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(wt[u], f[v]));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s_part[tid * VEC + v] = acc[v];
+            __syncthreads();
+            if (gi == 0 && c0 < D) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float a = s_part[gl * VEC + v];
+                    for (int g = 1; g < groups; ++g) a = __fadd_rn(a, s_part[(g * G + gl) * VEC + v]);
+                    w.partial[(int64_t)q * D + c0 + v] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T>
+inline void launch_spmm_pass(const int32_t* perm, const int64_t* col, const T* value, const T* mat, T* out, const Ws& w,
+                             int64_t nnz, int64_t D, int gshift, int kchunks, hipStream_t stream) {
+    const int ga = w.cap_p < 2048 ? w.cap_p : 2048;
+    hipLaunchKernelGGL((hub_partial_spmm_kernel<T>), dim3(ga), dim3(THREADS), 0, stream, perm, col, value, mat, w, D, gshift,
+                       kchunks);
+    const int64_t items = (int64_t)w.cap_h * kchunks;
+    const int gb = gnnops_grid_cap(gnnops_cdiv(items, THREADS >> gshift), 1024);
+    hipLaunchKernelGGL((hub_combine_kernel<T, GNNOPS_SUM>), dim3(gb), dim3(THREADS), 0, stream, out, (int64_t*)nullptr, w, nnz,
+                       D, gshift, kchunks, 0, 0);
+}
+
 // Push-form index_select (gather.hip / bucket.hip): a HOT table row — selected by more than T_HUB outputs — is stored
 // by one lane group, eight stores in flight, for all of its outputs (56 ms for a row selected 10^6 times, against 1.3 ms
 // for the whole op without it). Set aside in the same way, its outputs are written by a workgroup per piece instead:

@@ -14,6 +14,7 @@
 // roundings torch's `matrix[col] * value` followed by scatter_add perform; no FMA contraction.
 // 16-bit inputs: v*x is exact in fp32, acc in fp32, rounded once to the storage type.
 #include "common.h"
+#include "hub.h"
 
 namespace {
 
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ perm,
                                                         const int64_t* __restrict__ col, const T* __restrict__ value,
                                                         const T* __restrict__ mat, T* __restrict__ out, int64_t M,
-                                                        int64_t D, int gshift, int kchunks) {
+                                                        int64_t D, int gshift, int kchunks, hub::Ws hw, int hub_on) {
     constexpr int VEC = Elem<T>::VEC;
     const int G = 1 << gshift;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,6 +38,10 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
         const int64_t c0 = ((int64_t)chunk * G + gl) * VEC;
         if (c0 >= D) continue;
         const int32_t beg = rowptr[i], end = rowptr[i + 1];
+        if (hub_on && end - beg > hub::T_HUB) {  // a hub row (hub.h): multiplied out piecewise by the hub pass
+            if (gl == 0 && chunk == 0) hub::append(hw, (int)i, beg, end, end - beg);
+            continue;
+        }
         float acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
@@ -145,7 +150,8 @@ __global__ void permute_kernel(const U* __restrict__ in, const int32_t* __restri
 
 template <typename T>
 int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value, const void* mat,
-           void* out, int64_t M, int64_t D, int64_t mat_rows, hipStream_t stream) {
+           void* out, int64_t M, int64_t D, int64_t mat_rows, hipStream_t stream, int64_t nnz, void* hub_ws,
+           size_t hub_ws_bytes) {
     constexpr int VEC = Elem<T>::VEC;
     if (D % VEC == 0 && (uintptr_t)mat % 16 == 0 && (uintptr_t)out % 16 == 0) {
         const int64_t vecs = D / VEC;
@@ -156,12 +162,24 @@ int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const
         // a dense operand far beyond the 256 MiB Infinity Cache is streamed nontemporally (its rows would only evict
         // the CSR arrays); a smaller one keeps normal caching so repeated rows hit on-die
         const bool nt = (size_t)mat_rows * (size_t)D * sizeof(T) > ((size_t)2 << 30);
+        hub::Ws hw{};
+        int hub_on = 0;
+        if (hub_ws && nnz > hub::T_HUB) {
+            const hub::Layout hl = hub::layout(nnz, D, false);
+            if (hub_ws_bytes >= hl.total) {
+                hw = hub::make_ws(hub_ws, hl, nnz, false);
+                if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+                hub_on = 1;
+            }
+        }
         if (nt)
             hipLaunchKernelGGL((spmm_rows_kernel<T, true>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col,
-                               (const T*)value, (const T*)mat, (T*)out, M, D, gshift, kchunks);
+                               (const T*)value, (const T*)mat, (T*)out, M, D, gshift, kchunks, hw, hub_on);
         else
             hipLaunchKernelGGL((spmm_rows_kernel<T, false>), dim3(grid), dim3(256), 0, stream, rowptr, perm, col,
-                               (const T*)value, (const T*)mat, (T*)out, M, D, gshift, kchunks);
+                               (const T*)value, (const T*)mat, (T*)out, M, D, gshift, kchunks, hw, hub_on);
+        if (hub_on)
+            hub::launch_spmm_pass<T>(perm, col, (const T*)value, (const T*)mat, (T*)out, hw, nnz, D, gshift, kchunks, stream);
     } else if (D >= 256) {
         const int chunks = (int)gnnops_cdiv(D, 256 * 4);
         const int grid = gnnops_grid_cap(M * chunks, 256 * 32);
@@ -180,15 +198,23 @@ int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const
 extern "C" int gnnops_spmm(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value,
                            const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int64_t mat_rows, int dtype,
                            gnnops_stream_t s) {
+    return gnnops_spmm_hubs(rowptr, perm, col, value, mat, out, M, D, nnz, mat_rows, dtype, nullptr, 0, s);
+}
+
+// The same with rows of more than 8192 nonzeros set aside and multiplied out piecewise by whole workgroups (hub.h):
+// hub_workspace = gnnops_hub_workspace_bytes(nnz, D, 0) bytes, or NULL.
+extern "C" int gnnops_spmm_hubs(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value,
+                                const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int64_t mat_rows, int dtype,
+                                void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(M >= 0 && D >= 0 && nnz >= 0, GNNOPS_EINVAL, "spmm: negative size");
     GNNOPS_REQUIRE(nnz < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED, "spmm: nnz must be < 2^31");
     if (M * D == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(rowptr && out && (nnz == 0 || (col && mat)), GNNOPS_EINVAL, "spmm: null pointer");
     switch (dtype) {
-        case GNNOPS_F32: return launch<float>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream);
-        case GNNOPS_F16: return launch<__half>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream);
-        case GNNOPS_BF16: return launch<__hip_bfloat16>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream);
+        case GNNOPS_F32: return launch<float>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream, nnz, hub_workspace, hub_workspace_bytes);
+        case GNNOPS_F16: return launch<__half>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream, nnz, hub_workspace, hub_workspace_bytes);
+        case GNNOPS_BF16: return launch<__hip_bfloat16>(rowptr, perm, col, value, mat, out, M, D, mat_rows, stream, nnz, hub_workspace, hub_workspace_bytes);
     }
     gnnops_set_error("spmm: unknown dtype %d", dtype);
     return GNNOPS_EINVAL;

@@ -43,6 +43,7 @@ SIGNATURES = {
     "gnnops_fused_select_sum_workspace_bytes": (_sz, []),
     "gnnops_fused_index_select_sum": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
     "gnnops_spmm": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
+    "gnnops_spmm_hubs": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
     "gnnops_permute": (_ci, [_vp, _vp, _vp, _i64, _ci, _vp]),
     "gnnops_sort_workspace_bytes": (_sz, [_i64, _i64, _i64, _ci]),
     "gnnops_sort": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _ci, _ci, _vp, _sz, _vp]),

@@ -93,10 +93,14 @@ def _spmm_launch(rowptr, perm, col, value, matrix, m, dt, plan=None):
     D = matrix.size(1)
     out = torch.empty((m, D), dtype=matrix.dtype, device=matrix.device)
     value_c = value.contiguous() if value is not None else None
+    L = _lib.load()
+    hub_bytes = L.gnnops_hub_workspace_bytes(col.numel(), D, 0)   # rows with more than 8192 nonzeros: csrc/hub.h
+    hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=matrix.device) if hub_bytes else None
     with torch.cuda.device(matrix.device):
-        rc = _lib.load().gnnops_spmm(rowptr.data_ptr(), perm.data_ptr() if perm is not None else None, col.data_ptr(),
-                                     value_c.data_ptr() if value_c is not None else None, matrix.data_ptr(),
-                                     out.data_ptr(), m, D, col.numel(), matrix.size(0), dt, _stream())
+        rc = L.gnnops_spmm_hubs(rowptr.data_ptr(), perm.data_ptr() if perm is not None else None, col.data_ptr(),
+                                value_c.data_ptr() if value_c is not None else None, matrix.data_ptr(),
+                                out.data_ptr(), m, D, col.numel(), matrix.size(0), dt,
+                                hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream())
     check(rc, "spmm")
     return out
 

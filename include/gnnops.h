@@ -208,6 +208,11 @@ int gnnops_fused_index_select_sum(const void* input, const int64_t* index, float
 int gnnops_spmm(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value,
                 const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int64_t mat_rows, int dtype,
                 gnnops_stream_t stream);
+/* The same with rows of more than 8192 nonzeros set aside and multiplied out piecewise by whole workgroups (csrc/hub.h;
+ * re-associated fp32 sums for those rows only): hub_workspace = gnnops_hub_workspace_bytes(nnz, D, 0) bytes, or NULL. */
+int gnnops_spmm_hubs(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const void* value,
+                     const void* mat, void* out, int64_t M, int64_t D, int64_t nnz, int64_t mat_rows, int dtype,
+                     void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
 
 /* out[j] = in[perm[j]] (elements of 2, 4 or 8 bytes): materialises the CSR column / value arrays of a plan-ordered COO
  * operand once, so gnnops_spmm can be called with perm == NULL and stream them. */

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import TORCH_DT, assert_bits_equal, from_np, load_golden, to_np
+from helpers import TORCH_DT, assert_bits_equal, f32_of, from_np, load_golden, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -209,3 +209,32 @@ def test_sort_nd_non_last_dim_on_chip(gnnops, oracle):
         ev, ei = oracle.sort(x.numpy(), dim)
         assert_bits_equal(v.cpu().numpy(), ev, f"values d{dim}")
         assert_bits_equal(i.cpu().numpy(), ei, f"indices d{dim}")
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+def test_spmm_hub_rows(gnnops, oracle, dname):
+    """Output rows with more than 8192 nonzeros (csrc/hub.h) are multiplied out piecewise by whole workgroups: re-associated
+    fp32 sums for those rows (tolerance), every other row bit-exact; COO (plan) and CSR entry points."""
+    m, n, D, nnz = 500, 400, 64, 90000
+    g = torch.Generator().manual_seed(8)
+    row = torch.randint(0, m, (nnz,), generator=g)
+    r = torch.rand(nnz, generator=g)
+    row[r < 0.4] = 7
+    row[(r >= 0.4) & (r < 0.55)] = 300
+    col = torch.randint(0, n, (nnz,), generator=g)
+    idx = torch.stack([row, col])
+    val = (torch.rand(nnz, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    B = (torch.rand(n, D, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    exp = oracle.spmm(idx.numpy(), to_np(val), m, n, to_np(B), dtype=dname)
+    hubs = np.bincount(row.numpy(), minlength=m) > 8192
+    assert hubs.sum() == 2
+    order = torch.sort(row, stable=True).indices
+    rowptr = torch.zeros(m + 1, dtype=torch.int64)
+    rowptr[1:] = torch.bincount(row, minlength=m).cumsum(0)
+    for got in (gnnops.spmm(idx.cuda(), val.cuda(), m, n, B.cuda()),
+                gnnops.spmm_csr(rowptr.cuda(), col[order].cuda(), val[order].cuda(), B.cuda())):
+        gf = f32_of(to_np(got), dname) if dname != "f32" else to_np(got)
+        ef = f32_of(exp, dname) if dname != "f32" else exp
+        assert np.array_equal(to_np(got)[~hubs], exp[~hubs])
+        tol = 2e-3 if dname == "f32" else 0.5
+        np.testing.assert_allclose(gf[hubs], ef[hubs], rtol=1e-2 if dname != "f32" else 2e-4, atol=tol)
