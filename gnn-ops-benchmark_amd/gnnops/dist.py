@@ -79,10 +79,14 @@ class HipLocal:
         if n_rows == 0:
             return
         E, D = src.shape
+        L = _lib.load()
+        rcode = REDUCE_CODE["sum" if reduce == "add" else reduce]
+        hub_bytes = L.gnnops_hub_workspace_bytes(E, D, rcode)   # heavy destinations: csrc/hub.h
+        hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=src.device) if hub_bytes else None
         with torch.cuda.device(src.device):
-            check(_lib.load().gnnops_segment_reduce(src.data_ptr(), crow.data_ptr(), perm.data_ptr(), out.data_ptr(), None, 1,
-                                                    E, D, n_rows, _dtype_code(src, "sharded_scatter"),
-                                                    REDUCE_CODE["sum" if reduce == "add" else reduce], 0, _stream()),
+            check(L.gnnops_segment_reduce_hubs(src.data_ptr(), crow.data_ptr(), perm.data_ptr(), out.data_ptr(), None, 1,
+                                               E, D, n_rows, _dtype_code(src, "sharded_scatter"), rcode, 0,
+                                               hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream()),
                   "segment_reduce")
 
     def _split_windowed(self, src, index, n_total, lo, hi, reduce):
@@ -127,9 +131,12 @@ class HipLocal:
 
         def own(out=None):
             slab = out if out is not None else torch.empty((n_loc, D), dtype=src.dtype, device=dev)
+            hub_bytes = L.gnnops_hub_workspace_bytes(E, D, _lib.SUM)   # heavy destinations: csrc/hub.h
+            hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=dev) if hub_bytes else None
             with torch.cuda.device(dev):
-                check(L.gnnops_bucket_reduce(src.data_ptr(), ws.data_ptr(), slab.data_ptr(), None, E, D, n_loc, _lib.F32,
-                                             _lib.SUM, 0, _stream()), "bucket_reduce")
+                check(L.gnnops_bucket_reduce_hubs(src.data_ptr(), ws.data_ptr(), slab.data_ptr(), None, E, D, n_loc, _lib.F32,
+                                                  _lib.SUM, 0, hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes,
+                                                  _stream()), "bucket_reduce")
             return slab
 
         return own, ids, rows
