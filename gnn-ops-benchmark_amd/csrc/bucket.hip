@@ -201,8 +201,10 @@ __device__ __noinline__ int32_t hub_prepare(const uint32_t* __restrict__ keys, c
     return bbeg + (int32_t)running;
 }
 
+// (THREADS, 4): four waves per SIMD = 128 VGPRs. Sums need 121-125 anyway; min / max would take 129-137 and lose a wave
+// of occupancy for one register (fp32: fits without a spill; 16-bit min / max: two spilled registers).
 template <typename T, int R>
-__global__ __launch_bounds__(THREADS) void bucket_reduce_kernel(const T* __restrict__ src, const uint32_t* __restrict__ keys,
+__global__ __launch_bounds__(THREADS, 4) void bucket_reduce_kernel(const T* __restrict__ src, const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ vals,
                                                                 const int32_t* __restrict__ bptr, T* __restrict__ out,
                                                                 int64_t* __restrict__ arg_out, int64_t E, int64_t K,
