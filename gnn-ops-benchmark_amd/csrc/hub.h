@@ -197,7 +197,9 @@ __global__ __launch_bounds__(THREADS) void hub_partial_kernel(const T* __restric
                         }
                     }
                     w.partial[(int64_t)q * K + col + v] = a;
-                    if constexpr (IS_ARG) w.parg[(int64_t)q * K + col + v] = ar;
+                    if constexpr (IS_ARG) {
+                        if (w.parg) w.parg[(int64_t)q * K + col + v] = ar;
+                    }
                 }
             }
             __syncthreads();

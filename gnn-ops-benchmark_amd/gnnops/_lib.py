@@ -61,6 +61,7 @@ SIGNATURES = {
     "gnnops_rowptr_workspace_bytes": (_sz, [_i64]),
     "gnnops_rowptr_from_sorted": (_ci, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "gnnops_segment_composite": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp]),
+    "gnnops_segment_composite_hubs": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp, _sz, _vp]),
     "gnnops_addmm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gnnops_addmm": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
     "gnnops_fused_index_add_select_sum_workspace_bytes": (_sz, [_i64, _i64]),

@@ -129,10 +129,14 @@ def _composite(src, index, dim, dim_size, mode, param):
     if not per_source:
         shape[dim] = plan.N
     out = torch.empty(shape, dtype=src.dtype, device=src.device)
+    L = _lib.load()
+    hub_bytes = L.gnnops_hub_workspace_bytes(E, K, _lib.MIN) if B == 1 else 0   # groups with more than 8192 members: hub.h
+    hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=src.device) if hub_bytes else None
     with torch.cuda.device(src.device):
-        rc = _lib.load().gnnops_segment_composite(src.data_ptr(), plan.rowptr.data_ptr(),
-                                                  plan.perm.data_ptr() if plan.perm is not None else None, out.data_ptr(),
-                                                  B, E, K, plan.N, dt, _MODES[mode], float(param), _stream())
+        rc = L.gnnops_segment_composite_hubs(src.data_ptr(), plan.rowptr.data_ptr(),
+                                             plan.perm.data_ptr() if plan.perm is not None else None, out.data_ptr(),
+                                             B, E, K, plan.N, dt, _MODES[mode], float(param),
+                                             hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream())
     check(rc, "segment_composite")
     return out
 

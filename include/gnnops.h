@@ -317,6 +317,11 @@ int gnnops_rowptr_from_sorted(const int64_t* sorted_index, int64_t E, int64_t N,
 int gnnops_segment_composite(const void* src, const int32_t* rowptr, const int32_t* perm, void* out,
                              int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int mode, double param,
                              gnnops_stream_t stream);
+/* The same with groups of more than 8192 members set aside and processed piecewise by whole workgroups (csrc/hub.h);
+ * hub_workspace = gnnops_hub_workspace_bytes(E, K, GNNOPS_MIN) bytes, or NULL. B == 1, rows of whole 16-B lanes. */
+int gnnops_segment_composite_hubs(const void* src, const int32_t* rowptr, const int32_t* perm, void* out, int64_t B,
+                                  int64_t E, int64_t K, int64_t N, int dtype, int mode, double param,
+                                  void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
 
 #ifdef __cplusplus
 }
