@@ -72,6 +72,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+    # GNNOPS_BENCH_GLOO_ONE_GPU=1: rehearsal of the N>1 code path on a one-GPU box — every rank on cuda:0, gloo carrying
+    # the device tensors (RCCL refuses two ranks on one device). Its timings mean nothing; its JSON line says so.
+    rehearsal = os.environ.get("GNNOPS_BENCH_GLOO_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -85,7 +90,10 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     Nloc, E, D, _ = WORKLOADS[args.workload]
     Ntot = Nloc * world
@@ -161,6 +169,9 @@ def main():
             "pct_of_hbm_peak": round(100 * value / (HBM_PEAK_GBS * world), 2),
         },
     }
+
+    if rehearsal:
+        result["rehearsal"] = "every rank on cuda:0 over gloo: code-path check only, NOT a measurement"
 
     if dist is not None:
         def timed_variant(idx, exch, steps, warm=1):

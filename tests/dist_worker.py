@@ -124,3 +124,31 @@ def run(rank, world, init_file, n_total, e_local, d, out_dir):
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi, **res)
     finally:
         dist.destroy_process_group()
+
+
+def run_gpu(rank, world, init_file, n_total, e_local, d, out_dir):
+    """Two gloo ranks sharing cuda:0 with the real per-GPU pieces (gnnops.dist.HipLocal): the exchange carries device
+    tensors exactly as under RCCL (test_dist_gpu.py; a one-GPU box cannot hold two RCCL ranks)."""
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        import gnnops
+        from gnnops.dist import owned_rows, sharded_scatter, sharded_spmm
+
+        gnnops.load_library()
+        src, idx = make_inputs(rank, world, n_total, e_local, d)
+        src, idx = src.cuda(), idx.cuda()
+        res = {}
+        for r in ("sum", "min", "max", "mean", "mul"):
+            res["sparse_" + r] = sharded_scatter(src, idx, n_total, r).cpu().numpy()
+        slab = torch.full((n_total // world, d), 7.0, device="cuda")
+        got = sharded_scatter(src, idx, n_total, "sum", out_slab=slab)
+        assert got is slab
+        res["sparse_sum_out"] = slab.cpu().numpy()
+        res["dense_sum"] = sharded_scatter(src, idx, n_total, "sum", exchange="dense").cpu().numpy()
+        idx2, val, mat = make_spmm_inputs(rank, world, n_total, e_local, 40, d)
+        res["spmm"] = sharded_spmm(idx2.cuda(), val.cuda(), n_total, mat.cuda()).cpu().numpy()
+        lo, hi = owned_rows(n_total, rank, world)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi, **res)
+    finally:
+        dist.destroy_process_group()

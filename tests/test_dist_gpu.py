@@ -1,7 +1,7 @@
 """GPU parity of the per-rank pieces of gnnops.dist (HipLocal) — the split of one rank's edges into the own slab and the
 compact remote (id, row) lists, and the two ways the received lists are folded in — against the oracle, as if this GPU
 were rank 1 of 3 (destinations both below and above its range). The exchange itself is covered on CPU (test_dist_cpu.py,
-gloo) and by bench.py's one-rank RCCL rehearsal; this box has one GPU."""
+gloo), by bench.py's one-rank RCCL rehearsal, and end to end by the last test here: gloo ranks sharing this box's one GPU."""
 import numpy as np
 import pytest
 import torch
@@ -125,3 +125,17 @@ def test_sharded_scatter_single_rank_rccl(oracle):
                                        rtol=1e-6, atol=1e-6)
         finally:
             dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,n_total,e_local,d", [(2, 6000, 20000, 128), (3, 192, 500, 8)])
+def test_sharded_ops_gloo_ranks_on_one_gpu(world, n_total, e_local, d):
+    """sharded_scatter / sharded_spmm end to end with the real per-GPU pieces and DEVICE tensors in the exchange: `world`
+    gloo ranks sharing cuda:0 (RCCL refuses two ranks on one device); the first case takes the windowed partition."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import rehearse_dist_gloo_gpu
+
+    rehearse_dist_gloo_gpu.check(world, n_total, e_local, d)

@@ -1,0 +1,53 @@
+"""Rehearse gnnops.dist with the real per-GPU pieces on >1 rank of a ONE-GPU box: `world` gloo ranks all on cuda:0
+(RCCL refuses two ranks on one device). Checks every rank's slab against the oracle on the concatenated edges.
+usage: python tools/rehearse_dist_gloo_gpu.py [world=2] [n_total] [e_local] [d]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "tests"), ROOT, os.path.join(ROOT, "gnn-ops-benchmark_amd")):
+    sys.path.insert(0, p)
+import dist_worker  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def check(world, n_total, e_local, d):
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.run_gpu, args=(world, os.path.join(tmp, "init"), n_total, e_local, d, tmp), nprocs=world,
+                 join=True)
+        srcs, idxs = zip(*(dist_worker.make_inputs(r, world, n_total, e_local, d) for r in range(world)))
+        src, idx = torch.cat(srcs).numpy(), torch.cat(idxs).numpy()
+        parts = [dist_worker.make_spmm_inputs(r, world, n_total, e_local, 40, d) for r in range(world)]
+        gidx = np.concatenate([np.stack([p[0][0].numpy(), p[0][1].numpy() + 40 * r]) for r, p in enumerate(parts)], axis=1)
+        exp_spmm = oracle.spmm(gidx, np.concatenate([p[1].numpy() for p in parts]), n_total, 40 * world,
+                               np.concatenate([p[2].numpy() for p in parts], axis=0))
+        for rank in range(world):
+            got = np.load(os.path.join(tmp, f"rank{rank}.npz"))
+            lo, hi = int(got["lo"]), int(got["hi"])
+            for r in ("sum", "min", "max", "mean", "mul"):
+                exp = oracle.scatter(src, idx, dim=0, dim_size=n_total, reduce=r)
+                exp = exp[0] if isinstance(exp, tuple) else exp
+                if r in ("min", "max"):
+                    assert np.array_equal(got["sparse_" + r], exp[lo:hi]), r
+                else:
+                    np.testing.assert_allclose(got["sparse_" + r], exp[lo:hi], rtol=1e-5, atol=1e-5, err_msg=r)
+            assert np.array_equal(got["sparse_sum_out"], got["sparse_sum"])
+            exp = oracle.scatter(src, idx, dim=0, dim_size=n_total, reduce="sum")
+            np.testing.assert_allclose(got["dense_sum"], exp[lo:hi], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(got["spmm"], exp_spmm[lo:hi], rtol=1e-5, atol=1e-5)
+    print(f"ok world={world} n_total={n_total} e_local={e_local} d={d}", flush=True)
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:]]
+    world = a[0] if a else 2
+    if len(a) >= 4:
+        check(world, *a[1:4])
+    else:
+        check(world, 64 * world, 500, 8)
+        check(world, 3000 * world, 20000, 128)
