@@ -404,12 +404,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
 // 256 B/clk plus 32 KiB of DMA stores against 2 x 256 MFMA cycles per SIMD); the larger wave tile reads 12 KiB per 32
 // MFMAs instead of 8 KiB per 16 and halves the L2 -> LDS bytes per flop. Same four-stage counted-vmcnt pipeline as
 // gemm_dma4_kernel; stage = A [256][32] (a4_off image) + B [32][256] as two [32][128] half images (b_off).
+// VAR 2 (default): the two wave groups ping-pong (see the main loop); VAR 1 (GNNOPS_GEMM_VAR=1, kept for A/B runs with
+// tools/time_gemm_var.py): all eight waves in lockstep with a half-step software pipeline.
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int A2_BYTES = BM2 * BK4 * 2, B2_BYTES = BK4 * BN2 * 2, STAGE2_BYTES = A2_BYTES + B2_BYTES;  // 16 + 16 KiB
 constexpr int GEMM256_SMEM = NST * STAGE2_BYTES;                                                       // 128 KiB
 constexpr int EPI2_ROWS = 32;  // rows of a wave's 128 staged per epilogue round: 8 waves x 32 x CS x 4 B = 68 KiB
 
-template <typename T, bool IS_BF16>
+template <typename T, bool IS_BF16, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
                                                              const T* __restrict__ addend, T* __restrict__ C, int64_t M,
                                                              int64_t N, int64_t K, int64_t lda, int64_t ldb) {
@@ -442,14 +444,20 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
         b_src[p] = Bm + (int64_t)br * ldb + bcol;
         b_dst[p] = A2_BYTES + half * (B2_BYTES / 2) + (q & 7) * 1024;
     }
+    auto dma_a = [&](int stage, int64_t k0, int p) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE2_BYTES + (wave * 2 + p) * 1024),
+                                         16, 0, 0);
+    };
+    auto dma_b = [&](int stage, int64_t k0, int p) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE2_BYTES + b_dst[p]), 16, 0, 0);
+    };
     auto dma = [&](int stage, int64_t k0) {
-        unsigned char* base = smem + stage * STAGE2_BYTES;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
-                                             (__attribute__((address_space(3))) void*)(base + (wave * 2 + p) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
-                                             (__attribute__((address_space(3))) void*)(base + b_dst[p]), 16, 0, 0);
+            dma_a(stage, k0, p);
+            dma_b(stage, k0, p);
         }
     };
 
@@ -517,16 +525,105 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int64_t tn = kt + NST - 1;
-        dma((int)(tn & (NST - 1)), (tn < ksteps ? tn : ksteps - 1) * BK4);
+        const int stn = (int)(tn & (NST - 1));
+        const int64_t k0n = (tn < ksteps ? tn : ksteps - 1) * BK4;
         read_first(kt + 1, nblo, nbhi, af);  // past the end: a stale stage, never used
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mi = 4; mi < 8; ++mi)
+        for (int mi = 4; mi < 8; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
+            // one DMA piece behind every four MFMAs (issued right after the barrier they cost 3 % more)
+            if (mi & 1) dma_b(stn, k0n, (mi - 4) >> 1);
+            else dma_a(stn, k0n, (mi - 4) >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if constexpr (VAR == 2) {
+        // Ping-pong (the default): waves 0-3 and 4-7 — wave w and w + 4 share a SIMD — run half a K-step apart, so one
+        // partner's memory phase (16 fragment reads, 4 DMA pieces at ~100 cycles of issue each, their latency) runs under
+        // the other's 32 back-to-back MFMAs. Run in lockstep (VAR 1) both partners are in that phase together and the
+        // matrix pipe idles: 0.88 -> 0.79 ms at 8192^3 bf16. Still ONE barrier per K-step kt:
+        //   waves 0-3 reach it after the MFMAs of tile kt, waves 4-7 after reading tile kt's fragments (reads retired);
+        //   every wave has waited for its own DMA pieces of tile kt+1 (vmcnt(8): tiles kt+2, kt+3 stay in flight);
+        //   behind it waves 0-3 read tile kt+1 and refill tile kt's stage with tile kt+4, waves 4-7 multiply tile kt,
+        //   then read tile kt+1 and refill tile kt's stage too (their pieces of tile kt+4 = (kt+1)+3).
+        // Both groups execute 1 + ksteps barriers. Fragments are single-buffered: a wave's MFMAs have all issued before
+        // its next reads are.
+        s16x4 blo[4], bhi[4];
+        auto read_all = [&](int64_t t) {
+            const uint32_t st = (uint32_t)(t & (NST - 1)) * STAGE2_BYTES;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[ni]) : "v"(b_lo_off[ni] + st));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bhi[ni]) : "v"(b_hi_off[ni] + st));
+            }
+            const uint32_t aa = a_rd + st;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(af[1]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[2]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(af[3]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[4]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(af[5]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[6]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(af[7]) : "v"(aa));
+        };
+        auto wait_reads = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]),
+                           "+v"(bhi[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                           "+v"(af[6]), "+v"(af[7]));
+        };
+        auto compute = [&]() {
+            s16x8 bf[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                bf[ni] = s16x8{blo[ni].x, blo[ni].y, blo[ni].z, blo[ni].w, bhi[ni].x, bhi[ni].y, bhi[ni].z, bhi[ni].w};
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto dma_tile = [&](int64_t tn) { dma((int)(tn & (NST - 1)), (tn < ksteps ? tn : ksteps - 1) * BK4); };
+        dma_tile(0);
+        dma_tile(1);
+        dma_tile(2);
+        if (__builtin_amdgcn_readfirstlane(wave) < 4) {
+            dma_tile(3);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // own pieces of tile 0
+            __builtin_amdgcn_s_barrier();
+            read_all(0);
+            for (int64_t kt = 0; kt < ksteps; ++kt) {
+                wait_reads();
+                compute();
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // own pieces of tile kt+1; kt+2 and kt+3 stay in flight
+                __builtin_amdgcn_s_barrier();
+                read_all(kt + 1);   // past the end: a stale stage, never used
+                dma_tile(kt + 4);   // tile kt's stage: waves 4-7 retired their reads of it before the barrier
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int64_t kt = 0; kt < ksteps; ++kt) {
+                read_all(kt);
+                dma_tile(kt + 3);   // tile kt-1's stage: everyone read it before the previous barrier
+                wait_reads();
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                compute();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]),
+                       "+v"(bhi[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                       "+v"(af[6]), "+v"(af[7])
+                     :
+                     : "memory");
+    } else {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) dma(t, (int64_t)(t < ksteps ? t : ksteps - 1) * BK4);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -543,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
                    "+v"(bh0[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
                  :
                  : "memory");
+    }
     __syncthreads();  // all DMA (including the redundant tail fetches) landed, all reads done: the stages become the epilogue's
 
     float* ctile = reinterpret_cast<float*>(smem) + wave * (EPI2_ROWS * CS);
@@ -572,20 +670,28 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
     }
 }
 
-template <typename T, bool IS_BF16>
-int launch_dma256(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K,
+template <typename T, bool IS_BF16, int VAR>
+int launch_dma256_var(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K,
                   int64_t lda, int64_t ldb, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma256_kernel<T, IS_BF16>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma256_kernel<T, IS_BF16, VAR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_SMEM) != hipSuccess)
             return gnnops_check_launch("addmm attribute");
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_dma256_kernel<T, IS_BF16>), dim3((unsigned)gnnops_cdiv(N, BN2), (unsigned)gnnops_cdiv(M, BM2)), dim3(512),
+    hipLaunchKernelGGL((gemm_dma256_kernel<T, IS_BF16, VAR>), dim3((unsigned)gnnops_cdiv(N, BN2), (unsigned)gnnops_cdiv(M, BM2)), dim3(512),
                        GEMM256_SMEM, stream, (const uint16_t*)mat1, (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K,
                        lda, ldb);
     return gnnops_check_launch("addmm");
+}
+
+template <typename T, bool IS_BF16>
+int launch_dma256(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K,
+                  int64_t lda, int64_t ldb, hipStream_t stream) {
+    const char* var = getenv("GNNOPS_GEMM_VAR");
+    if (var && var[0] == '1') return launch_dma256_var<T, IS_BF16, 1>(input, mat1, mat2, out, M, N, K, lda, ldb, stream);
+    return launch_dma256_var<T, IS_BF16, 2>(input, mat1, mat2, out, M, N, K, lda, ldb, stream);
 }
 
 // ---- fp32 operands: v_mfma_f32_16x16x4_f32 (exact fp32 products and sums, 1/16 of the bf16 MFMA rate = the fp32

@@ -8,7 +8,7 @@ import gnnops
 L = 8192
 g = torch.Generator(device="cuda").manual_seed(1)
 a, b, c = [(torch.rand(L, L, generator=g, device="cuda") * 2 - 1).to(torch.bfloat16) for _ in range(3)]
-for sw in ("0", "3", "1"):
+for sw in ("0", "3", "1"):  # 0 = default ladder (256 x 256 ping-pong at this size)
     os.environ["GNNOPS_GEMM_NO_DMA"] = sw
     for _ in range(3):
         out = gnnops.addmm(c, a, b)
