@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
     }
 }
 
-// 256 x 256 block tile, eight waves of 128 x 64 — for problems with at least one such tile per CU. At 128 x 128 / 64 x 64
+// 256 x 256 block tile, eight waves of 128 x 64 — for problems with at least 128 such tiles (half the CUs busy with
+// this kernel already beat 128 x 128 tiles on all of them: gemm_plan). At 128 x 128 / 64 x 64
 // per wave the LDS array is as busy as the MFMA pipe (per K-step of 32 and per CU: 8 waves x 8 KiB of fragment reads at
 // 256 B/clk plus 32 KiB of DMA stores against 2 x 256 MFMA cycles per SIMD); the larger wave tile reads 12 KiB per 32
 // MFMAs instead of 8 KiB per 16 and halves the L2 -> LDS bytes per flop. Same four-stage counted-vmcnt pipeline as
@@ -864,7 +865,9 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
     const bool aligned = M % BM == 0 && N % BN == 0 && K % BK == 0;
     const bool dma = K > 0 && !(sw && sw[0] == '1') && (aligned || (M >= 512 && N >= 512 && K >= 256));
     if (dma) {
-        g.path = (gnnops_cdiv(M, BM2) * gnnops_cdiv(N, BN2) >= 256 && !(sw && sw[0] == '3')) ? 2 : 1;
+        const char* mn = getenv("GNNOPS_GEMM_MIN256");  // A/B: least number of 256 x 256 tiles that takes the big-tile kernel
+        const int64_t min256 = mn ? atoll(mn) : 128;  // measured: 144 tiles 0.062 vs 0.086 ms, 100 tiles 0.056 vs 0.046 (tools/time_gemm_tiles.py)
+        g.path = (gnnops_cdiv(M, BM2) * gnnops_cdiv(N, BN2) >= min256 && !(sw && sw[0] == '3')) ? 2 : 1;
         g.Kp = round_up(K, 64);
         g.copy_a = K % 64 != 0;
         g.copy_b = K % 64 != 0 || N % 8 != 0;
