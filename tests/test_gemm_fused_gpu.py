@@ -61,9 +61,10 @@ def test_addmm_identity_layout(gnnops):
 
 @pytest.mark.parametrize("dname", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 64), (4096, 4096, 192), (8192, 2048, 128), (2048, 8192, 320),
-                                   (4099, 4101, 300), (4090, 4092, 263), (1581, 1581, 1581), (700, 900, 257), (513, 520, 512)])
+                                   (4099, 4101, 300), (4090, 4092, 263), (1581, 1581, 1581), (700, 900, 257), (513, 520, 512),
+                                   (3000, 3100, 264), (2816, 2816, 128)])
 def test_addmm_big_tiles(gnnops, M, N, K, dname):
-    """The LDS-DMA kernels: >= 256 tiles of 256 x 256 take the eight-wave kernel (K = 64: fewer K-steps than pipeline
+    """The LDS-DMA kernels: >= 128 tiles of 256 x 256 take the eight-wave ping-pong kernel (K = 64: fewer K-steps than pipeline
     stages), smaller grids the 128 x 128 one; odd M / N / K exercise the filler rows, the zero-padded K tail and the
     8-B / per-element epilogue stores. Same bound as test_addmm_matmul against a float64 product of the same 16-bit
     operands."""
