@@ -730,11 +730,11 @@ __device__ inline f32x4 load4f(const float* __restrict__ base, int64_t r, int64_
     return v;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                           const float* __restrict__ addend, float* __restrict__ C,
                                                           int64_t M, int64_t N, int64_t K, bool a_vec, bool b_vec) {
     constexpr int STAGE_F = BM * FAS + FBK * FBS;       // floats per stage (2560 + 2304)
-    constexpr int EPI_F = 4 * 64 * CS;
+    constexpr int EPI_F = 4 * 32 * CS;
     constexpr int SMEM_F = (2 * STAGE_F > EPI_F) ? 2 * STAGE_F : EPI_F;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
 
@@ -797,35 +797,42 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
         __syncthreads();
     }
 
-    float* ctile = smem + wave * (64 * CS);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ctile[(mi * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[mi][ni][r];
-    __builtin_amdgcn_wave_barrier();
+    // epilogue: each wave stages its 64 x 64 tile through LDS in two rounds of 32 rows, so the staging area (34 KiB) stays
+    // below the main loop's two stages (38 KiB) and three workgroups share a CU (one round of 64 rows: 68 KiB, two).
+    // The K loop ended on a barrier: every wave is done with the stages.
+    float* ctile = smem + wave * (32 * CS);
     const bool vec_c = (N % 4 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
     const int pr = lane >> 4, pc = (lane & 15) * 4;  // 16 lanes x 4 columns per row, 4 rows per pass
 #pragma unroll
-    for (int pass = 0; pass < 16; ++pass) {
-        const int rr = pass * 4 + pr;
-        const int64_t row = m0 + wr * 64 + rr;
-        const int64_t col = n0 + wc * 64 + pc;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
-        if (row >= M || col >= N) continue;
-        if (vec_c && col + 4 <= N) {
-            if (addend) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * N + col);
-                v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];
-            }
-            *reinterpret_cast<f32x4*>(C + row * N + col) = v;
-        } else {
+    for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * N + col + i] : 0.f);
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ctile[(h * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[c * 2 + h][ni][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int rr = pass * 4 + pr;
+            const int64_t row = m0 + wr * 64 + c * 32 + rr;
+            const int64_t col = n0 + wc * 64 + pc;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
+            if (row >= M || col >= N) continue;
+            if (vec_c && col + 4 <= N) {
+                if (addend) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * N + col);
+                    v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];
+                }
+                *reinterpret_cast<f32x4*>(C + row * N + col) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * N + col + i] : 0.f);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

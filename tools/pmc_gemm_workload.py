@@ -12,5 +12,10 @@ for sw in ("0", "3", "1"):  # 0 = default ladder (256 x 256 ping-pong at this si
     os.environ["GNNOPS_GEMM_NO_DMA"] = sw
     for _ in range(3):
         out = gnnops.addmm(c, a, b)
+os.environ["GNNOPS_GEMM_NO_DMA"] = "0"
+a32, b32, c32 = [torch.rand(L, L, generator=g, device="cuda") * 2 - 1 for _ in range(3)]
+for _ in range(3):
+    out = gnnops.addmm(c32, a32, b32)   # gemm_f32_kernel
+    ref = torch.addmm(c32, a32, b32)    # the library's fp32 kernel, for the same counters
 torch.cuda.synchronize()
 print("done")
