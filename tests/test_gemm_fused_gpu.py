@@ -198,3 +198,32 @@ def test_aten_sparse_and_scatter_reduce_overrides(gnnops, monkeypatch):
         assert calls["mm"] >= 2
     if "_coalesce@SparseCUDA" in aten.routed_ops:
         assert calls["coalesce"] >= 1
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 900, 257), (3000, 3100, 264), (1581, 1581, 1581), (4099, 4101, 300), (4096, 4100, 256),
+                                   (2052, 4096, 1000)])
+def test_addmm_rows_and_columns_do_not_leak(gnnops, M, N, K):
+    """Odd shapes reach the LDS-DMA kernels through zero-padded K tails, filler rows and clamped column chunks, and 0 x Inf
+    or 0 x NaN would poison valid outputs if any of that leaked: a NaN row of A may touch only that output row, an Inf
+    column of B only that output column — including the LAST row / column and the first column (the neighbour in memory of
+    the previous row's last one) — and everything else must match the float64 product."""
+    g = torch.Generator().manual_seed(9)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).half()
+    B = (torch.rand(K, N, generator=g) * 2 - 1).half()
+    A[3, :] = float("nan")
+    A[M - 1, :] = float("nan")
+    B[:, 0] = float("inf")       # first column: sits right behind column N-1 of the previous row in memory
+    B[:, N - 1] = float("inf")
+    got = gnnops.matmul(A.cuda(), B.cuda()).cpu().double()
+    rows = torch.ones(M, dtype=torch.bool)
+    rows[[3, M - 1]] = False
+    cols = torch.ones(N, dtype=torch.bool)
+    cols[[0, N - 1]] = False
+    assert bool(torch.isnan(got[~rows]).all())
+    assert bool((~torch.isfinite(got[:, ~cols])).all())
+    clean = got[rows][:, cols]
+    assert bool(torch.isfinite(clean).all())
+    Ac, Bc = A[rows].double(), B[:, cols].double()
+    ref = Ac @ Bc
+    bound = 2.0 ** -10 * ref.abs() + 4 * K * 2.0 ** -24 * (Ac.abs() @ Bc.abs()) + 1e-30
+    assert bool(((clean - ref).abs() <= bound).all())
