@@ -388,6 +388,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
     const bool vec_c = (N % 8 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
     const bool half_c = (N % 4 == 0) && ((uintptr_t)C % 8 == 0) && (addend == nullptr || (uintptr_t)addend % 8 == 0);
     const int pr = lane >> 3, pc = (lane & 7) * 8;
+    // interior tile with an addend: its 8 pieces per lane are requested together (one round trip instead of one per pass)
+    const bool pre_ok = vec_c && addend != nullptr && m0 + BM <= M && n0 + BN <= N;
+    u32x4 pre[8];
+    if (pre_ok) {
+        const T* ap = addend + (m0 + wr * 64 + pr) * N + n0 + wc * 64 + pc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pre[i] = *reinterpret_cast<const u32x4*>(ap + (int64_t)i * 8 * N);
+    }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int rr = pass * 8 + pr;
@@ -395,7 +403,16 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
         const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
         f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        epi_store8<T>(C, addend, m0 + wr * 64 + rr, n0 + wc * 64 + pc, M, N, f, vec_c, half_c);
+        const int64_t row = m0 + wr * 64 + rr, col = n0 + wc * 64 + pc;
+        if (pre_ok) {
+            float g[8];
+            Elem<T>::unpack(pre[pass], g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] += g[i];
+            *reinterpret_cast<u32x4*>(C + row * N + col) = Elem<T>::pack(f);
+        } else {
+            epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c);
+        }
     }
 }
 
