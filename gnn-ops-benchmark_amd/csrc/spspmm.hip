@@ -7,7 +7,7 @@
 //            block sums -> exclusive scan -> total P (the caller sizes the expansion from it)
 //   expand   product p of nonzero a: row = rowA[a], col = colB[e], val = round(valA[a] * valB[e]), e walking
 //            B's row in stored order; p enumerates (a, e) lexicographically
-//   compress gnnops_coalesce on the expansion: stable 64-bit radix sort by row*n+col, duplicates summed in
+//   compress gnnops_coalesce on the expansion: stable 64-bit radix sort by (row, col) packed as row << bits(n) | col, duplicates summed in
 //            expansion order (fp32) -> coalesced COO, bit-reproducible
 // Index-heavy and HBM-bound; nothing here is a dense contraction.
 #include "common.h"
