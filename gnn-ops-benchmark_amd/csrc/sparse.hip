@@ -21,14 +21,18 @@ constexpr int SCAN_IPT = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_IPT;
 
 // key = row << cbits | col (cbits = bits of n-1): the order of row * n + col, taken apart again by shift and mask
+// K = uint32_t when row and column bits fit 32 (the reference's shapes): the sort then moves 8 instead of 12 B per entry
+template <typename K>
 __global__ void build_coo_keys_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
-                                      uint64_t* __restrict__ keys, int64_t nnz, int cbits) {
-    GRID_STRIDE(i, nnz) keys[i] = ((uint64_t)row[i] << cbits) | (uint64_t)col[i];
+                                      K* __restrict__ keys, int64_t nnz, int cbits) {
+    GRID_STRIDE(i, nnz) keys[i] = (K)(((uint64_t)row[i] << cbits) | (uint64_t)col[i]);
 }
 
-__device__ inline bool is_head(const uint64_t* keys, int64_t p) { return p == 0 || keys[p] != keys[p - 1]; }
+template <typename K>
+__device__ inline bool is_head(const K* keys, int64_t p) { return p == 0 || keys[p] != keys[p - 1]; }
 
-__global__ __launch_bounds__(SCAN_THREADS) void count_heads_kernel(const uint64_t* __restrict__ keys, int64_t nnz,
+template <typename K>
+__global__ __launch_bounds__(SCAN_THREADS) void count_heads_kernel(const K* __restrict__ keys, int64_t nnz,
                                                                    uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t s_tmp[SCAN_THREADS / 64];
     const int64_t p0 = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
@@ -62,7 +66,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint32_t* __res
 // offset + heads of earlier rounds + heads of earlier waves (LDS) + heads of lower lanes (ballot), so the lanes of a wave
 // store to consecutive slots. (One thread per 8 consecutive positions, each storing its heads one by one, took 266-294 us
 // at the reference's spspmm shape — 8.8M positions, nearly all heads — against 60 us for this form.)
-__global__ __launch_bounds__(SCAN_THREADS) void emit_heads_kernel(const uint64_t* __restrict__ keys, int64_t nnz,
+template <typename K>
+__global__ __launch_bounds__(SCAN_THREADS) void emit_heads_kernel(const K* __restrict__ keys, int64_t nnz,
                                                                   int cbits, const uint32_t* __restrict__ block_off,
                                                                   int64_t* __restrict__ out_row,
                                                                   int64_t* __restrict__ out_col,
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void emit_heads_kernel(const uint64_t
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
     const uint64_t cmask = (1ull << cbits) - 1;
-    uint64_t k[SCAN_IPT];
+    K k[SCAN_IPT];
     uint64_t below[SCAN_IPT];  // ballot of heads among this wave's lanes, per round
 #pragma unroll
     for (int j = 0; j < SCAN_IPT; ++j) {
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void emit_heads_kernel(const uint64_t
         }
         if ((below[j] >> lane) & 1ull) {
             const uint32_t u = run + before + (uint32_t)__popcll(below[j] & ((1ull << lane) - 1));
-            out_row[u] = (int64_t)(k[j] >> cbits);
-            out_col[u] = (int64_t)(k[j] & cmask);
+            out_row[u] = (int64_t)((uint64_t)k[j] >> cbits);
+            out_col[u] = (int64_t)((uint64_t)k[j] & cmask);
             seg_start[u] = (uint32_t)(base + j * SCAN_THREADS + threadIdx.x);
         }
         run += total;
@@ -154,6 +159,45 @@ inline int bits_of(int64_t count) {  // bits that hold 0 .. count-1 (at least 1)
     return b;
 }
 
+inline int sort_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, int64_t n, int shift, uint32_t* th,
+                     uint32_t* dt, int tiles, hipStream_t st) {
+    return vi ? sortengine::pass_u32(ki, vi, ko, vo, n, shift, th, dt, tiles, st)
+              : sortengine::pass_first_u32(ki, ko, vo, n, shift, th, dt, tiles, st);
+}
+inline int sort_pass(const uint64_t* ki, const uint32_t* vi, uint64_t* ko, uint32_t* vo, int64_t n, int shift, uint32_t* th,
+                     uint32_t* dt, int tiles, hipStream_t st) {
+    return vi ? sortengine::pass_u64(ki, vi, ko, vo, n, shift, th, dt, tiles, st)
+              : sortengine::pass_first_u64(ki, ko, vo, n, shift, th, dt, tiles, st);
+}
+
+// keys, stable LSD sort over the key bits in use, head count and compaction; *sorted_vals = the payload in sorted order
+// (the permutation, or `carried` — the caller's scalar values — when given)
+template <typename K>
+int sort_and_compact(const int64_t* row, const int64_t* col, const uint32_t* carried, int64_t nnz, int cbits, int rbits,
+                     K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* tile_hist, uint32_t* digit_total,
+                     int tiles, uint32_t* block_sums, int nb, int64_t* d_count, int64_t* out_row, int64_t* out_col,
+                     uint32_t* seg_start, const uint32_t** sorted_vals, hipStream_t stream) {
+    hipLaunchKernelGGL(build_coo_keys_kernel<K>, dim3(grid_for(nnz)), dim3(256), 0, stream, row, col, keys_b, nnz, cbits);
+    const int passes = (cbits + rbits + 7) / 8;  // 8-bit passes over the key bits in use
+    K* kin = keys_b;
+    K* kout = keys_a;
+    const uint32_t* vin = carried;
+    uint32_t* vout = vals_a;
+    for (int p = 0; p < passes; ++p) {
+        const int rc = sort_pass(kin, vin, kout, vout, nnz, 8 * p, tile_hist, digit_total, tiles, stream);
+        if (rc) return rc;
+        K* tk = kin; kin = kout; kout = tk;
+        vin = vout;
+        vout = (vout == vals_a) ? vals_b : vals_a;
+    }
+    hipLaunchKernelGGL(count_heads_kernel<K>, dim3(nb), dim3(SCAN_THREADS), 0, stream, (const K*)kin, nnz, block_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, block_sums, nb, d_count);
+    hipLaunchKernelGGL(emit_heads_kernel<K>, dim3(nb), dim3(SCAN_THREADS), 0, stream, (const K*)kin, nnz, cbits, block_sums,
+                       out_row, out_col, seg_start);
+    *sorted_vals = vin;
+    return GNNOPS_OK;
+}
+
 }  // namespace
 
 // workspace: keys_a[nnz] u64 | keys_b[nnz] u64 | vals_a[nnz] u32 | vals_b[nnz] u32 | tile_hist | digit_total |
@@ -196,33 +240,18 @@ extern "C" int gnnops_coalesce(const int64_t* row, const int64_t* col, const voi
 
     const int cbits = bits_of(n), rbits = bits_of(m);
     GNNOPS_REQUIRE(cbits + rbits <= 64, GNNOPS_EUNSUPPORTED, "coalesce: m x n does not fit a 64-bit key");
-    hipLaunchKernelGGL(build_coo_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, stream, row, col, keys_b, nnz, cbits);
-    const int passes = (cbits + rbits + 7) / 8;  // 8-bit passes over the key bits in use
-    uint64_t* kin = keys_b;
-    uint64_t* kout = keys_a;
-    uint32_t* vin = nullptr;
-    uint32_t* vout = vals_a;
     // scalar fp32 values (the reference's case) ride through the sort as the 32-bit payload themselves, so the run
     // reduction streams them instead of gathering value[perm[p]]; the stable order of equal keys is the same either way
     const bool carry_values = value != nullptr && C == 1 && dtype == GNNOPS_F32;
-    for (int p = 0; p < passes; ++p) {
-        int rc;
-        if (p == 0 && carry_values)
-            rc = sortengine::pass_u64(kin, (const uint32_t*)value, kout, vout, nnz, 0, tile_hist, digit_total, tiles, stream);
-        else if (p == 0)
-            rc = sortengine::pass_first_u64(kin, kout, vout, nnz, 0, tile_hist, digit_total, tiles, stream);
-        else
-            rc = sortengine::pass_u64(kin, vin, kout, vout, nnz, 8 * p, tile_hist, digit_total, tiles, stream);
-        if (rc) return rc;
-        uint64_t* tk = kin; kin = kout; kout = tk;
-        uint32_t* nv = (vout == vals_a) ? vals_b : vals_a;
-        vin = vout; vout = nv;
-    }
-    // kin / vin: sorted keys and the permutation
-    hipLaunchKernelGGL(count_heads_kernel, dim3(nb), dim3(SCAN_THREADS), 0, stream, kin, nnz, block_sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, block_sums, nb, d_count);
-    hipLaunchKernelGGL(emit_heads_kernel, dim3(nb), dim3(SCAN_THREADS), 0, stream, kin, nnz, cbits, block_sums, out_row,
-                       out_col, seg_start);
+    const uint32_t* vin = nullptr;  // after the sort: the permutation (or the carried values)
+    const int rc = cbits + rbits <= 32
+                       ? sort_and_compact<uint32_t>(row, col, carry_values ? (const uint32_t*)value : nullptr, nnz, cbits, rbits,
+                                                    (uint32_t*)keys_a, (uint32_t*)keys_b, vals_a, vals_b, tile_hist, digit_total,
+                                                    tiles, block_sums, nb, d_count, out_row, out_col, seg_start, &vin, stream)
+                       : sort_and_compact<uint64_t>(row, col, carry_values ? (const uint32_t*)value : nullptr, nnz, cbits, rbits,
+                                                    keys_a, keys_b, vals_a, vals_b, tile_hist, digit_total, tiles, block_sums, nb,
+                                                    d_count, out_row, out_col, seg_start, &vin, stream);
+    if (rc) return rc;
     if (value && C > 0) {
         const int grid = grid_for(nnz * C);
         switch (dtype) {

@@ -103,7 +103,9 @@ def test_spmm_bit_exact(gnnops, oracle, m, n, D, nnz, dname):
 
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
 @pytest.mark.parametrize("m,n,nnz,dup", [(120, 100, 5000, 4), (12000 * 8, 12000 * 8, 40000, 8), (1, 1, 100, 1), (5, 7, 0, 1),
-                                         (3_000_000, 1, 50000, 2)])
+                                         (3_000_000, 1, 50000, 2),
+                                         (65536, 65536, 30000, 3),    # row + column bits = 32: the last shape with 32-bit keys
+                                         (65537, 65536, 30000, 3)])   # 33 bits: 64-bit keys
 def test_coalesce_and_transpose(gnnops, oracle, m, n, nnz, dup, dname):
     g = torch.Generator().manual_seed(6)
     idx = torch.stack([torch.randint(0, m, (nnz,), generator=g), torch.randint(0, n, (nnz,), generator=g)])
