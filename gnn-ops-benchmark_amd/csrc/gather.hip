@@ -283,12 +283,15 @@ int launch_select_k1(const void* in, const int64_t* index, void* out, int64_t B,
     return gnnops_check_launch("index_select");
 }
 
-inline int gather_lds_width(int64_t N, int64_t K, int64_t E, int elem_bytes) {
+inline int gather_lds_width(int64_t N, int64_t K, int64_t E, int elem_bytes, int64_t B = 1) {
     if (N <= 0 || (size_t)N * elem_bytes > GL_BUDGET) return 0;
     int64_t tc = (int64_t)(GL_BUDGET / ((size_t)N * elem_bytes));
     if (tc > K) tc = K;
     if (tc > 64) tc = 64;
     if (tc >= 8) tc &= ~(int64_t)7;
+    // a short table would fit in few wide strips — (1224)^2 fp16: 20 workgroups on 256 CUs, 45 us — so narrow them (not
+    // below 16 B per row) until there is about a workgroup per CU
+    while (tc >= 16 && B * gnnops_cdiv(K, tc) < 256) tc = (tc >> 1) & ~(int64_t)7;  // stays a multiple of 8, at least 8
     if (tc * elem_bytes < 8 && K * elem_bytes >= 8) return 0;  // strips under 8 bytes waste most of every line
     // staging reads the whole strip (N * elem bytes per column); gathering from HBM costs a 32-B sector per selected
     // element: stage unless fewer than one element per sector-equivalent of the strip is selected
@@ -587,7 +590,7 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
             }
         }
         // a row index with K > 1 is already coalesced along k in the element kernel; LDS staging pays for K == 1 rows
-        if (const int tc = gather_lds_width(N, K, E, elem_bytes);
+        if (const int tc = gather_lds_width(N, K, E, elem_bytes, B);
             tc > 0 && K * elem_bytes <= 8 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31)) {
             switch (elem_bytes) {
                 case 1: return launch_gather_lds<uint8_t, false>(input, index, out, B, N, K, E, tc, stream);
@@ -682,7 +685,7 @@ extern "C" int gnnops_gather(const void* input, const int64_t* index, void* out,
                    "gather: elem_bytes %d", elem_bytes);
     if (B * E * K == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(input && index && out, GNNOPS_EINVAL, "gather: null pointer");
-    const int tc = gather_lds_width(N, K, E, elem_bytes);
+    const int tc = gather_lds_width(N, K, E, elem_bytes, B);
     const bool lds = tc > 0 && B * gnnops_cdiv(K, tc) < ((int64_t)1 << 31);
     const int grid = gnnops_grid_cap(gnnops_cdiv(B * E * K, 256), 256 * 32);
 #define GATHER_CASE(U)                                                                                              \
