@@ -452,7 +452,7 @@ inline bool small_cells(int reduce, int elem_bytes, int64_t E) {
     return (reduce == GNNOPS_MIN || reduce == GNNOPS_MAX) && elem_bytes == 2 && E < 65535;
 }
 
-inline LdsGeom lds_geometry(int64_t N, int64_t K, int reduce, bool small_cell = false) {
+inline LdsGeom lds_geometry(int64_t N, int64_t K, int reduce, bool small_cell = false, int64_t B = 1) {
     const size_t per = (reduce == GNNOPS_SUM || reduce == GNNOPS_MUL || small_cell) ? 4 : 8;
     LdsGeom g{0, 0, 0};
     if (N <= 0) return g;
@@ -461,6 +461,10 @@ inline LdsGeom lds_geometry(int64_t N, int64_t K, int reduce, bool small_cell = 
         if (tc > K) tc = K;
         if (tc > 64) tc = 64;
         if (tc >= 4) tc &= ~(int64_t)3;      // whole 8-B / 32-B pieces of a row
+        // few destinations: the strips would be wide and few ((1000)^2: 28 workgroups on 256 CUs) — narrow them until there
+        // is about a workgroup per CU (GNNOPS_LDS_NARROW=0 keeps the wide strips, for A/B runs)
+        static const bool narrow = !(getenv("GNNOPS_LDS_NARROW") && getenv("GNNOPS_LDS_NARROW")[0] == '0');
+        while (narrow && tc >= 8 && B * gnnops_cdiv(K, tc) < 192) tc = (tc >> 1) & ~(int64_t)3;
         if (tc >= 2 || K < 2) return LdsGeom{(int)tc, N, 1};
     }
     const int64_t tc = K < 4 ? K : 4;
@@ -539,7 +543,7 @@ int run(const void* src_, const int64_t* index, void* out_, int64_t* arg_out, in
     constexpr bool IS_F32 = sizeof(T) == 4;
     char* w = (char*)workspace;
 
-    if (const LdsGeom g = lds_geometry(N, K, reduce, small_cells(reduce, (int)sizeof(T), E));
+    if (const LdsGeom g = lds_geometry(N, K, reduce, small_cells(reduce, (int)sizeof(T), E), B);
         g.tc > 0 && B * gnnops_cdiv(K, g.tc) * g.nchunks < ((int64_t)1 << 31) && E < ((int64_t)1 << 31))
         return dispatch_lds<T>(reduce, src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
 
