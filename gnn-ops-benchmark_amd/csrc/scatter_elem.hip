@@ -125,16 +125,19 @@ __global__ void scatter_mul_f32acc_kernel(const T* __restrict__ src, const int64
     }
 }
 
-// arg pass: smallest e whose value equals the reduced value.
+// arg pass: smallest e whose value equals the reduced value. A contribution equal to the reduce's identity (+inf for min,
+// -inf for max) never takes a slot — the sequential loop replaces on a strict improvement only — so a group that
+// received nothing else stays "empty" (arg = E, value 0), exactly as in the row kernels (segment.hip, bucket.hip).
 template <typename T>
 __global__ void scatter_arg_kernel(const T* __restrict__ src, const int64_t* __restrict__ index,
                                    const T* __restrict__ out, int64_t* __restrict__ arg_out, int64_t B, int64_t E,
-                                   int64_t K, int64_t N) {
+                                   int64_t K, int64_t N, float ident) {
     GRID_STRIDE(o, B * E * K) {
         int64_t b, e, k;
         decode(o, E, K, b, e, k);
         const int64_t d = (b * N + index[o]) * K + k;
-        if (Elem<T>::load(src + o) == Elem<T>::load(out + d))
+        const float v = Elem<T>::load(src + o);
+        if (v != ident && v == Elem<T>::load(out + d))
             atomicMin(reinterpret_cast<unsigned long long*>(arg_out + d), (unsigned long long)e);
     }
 }
@@ -399,7 +402,9 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
                 const int64_t e = e0 + (int64_t)u * rpi;
                 const int64_t d = nl[u] - n_lo;
                 const float v = Elem<T>::load(&vt[u]);
-                if (e >= E || d < 0 || d >= nloc || v != v) continue;
+                // NaNs never win, and neither does the reduce's identity (+inf for min, -inf for max): the sequential loop
+                // replaces on a strict improvement only, so a group fed nothing else stays empty — as in segment.hip
+                if (e >= E || d < 0 || d >= nloc || v != v || v == (IS_MIN ? __builtin_huge_valf() : -__builtin_huge_valf())) continue;
                 const CellT pos = (CellT)(e + 1);
                 const CellT lo = IS_MIN ? pos : (CellT)(~pos & LO_MASK);
                 const CellT w = (CellT)((order_image<CellT, T>(&vt[u], v) << HB) | lo);
@@ -593,7 +598,8 @@ int run(const void* src_, const int64_t* index, void* out_, int64_t* arg_out, in
     if (arg_out) {
         hipLaunchKernelGGL(fill_i64_kernel, dim3(go), dim3(256), 0, stream, arg_out, nout, E);
         if (nsrc > 0)
-            hipLaunchKernelGGL((scatter_arg_kernel<T>), dim3(gs), dim3(256), 0, stream, src, index, out, arg_out, B, E, K, N);
+            hipLaunchKernelGGL((scatter_arg_kernel<T>), dim3(gs), dim3(256), 0, stream, src, index, out, arg_out, B, E, K, N,
+                               reduce == GNNOPS_MIN ? __builtin_huge_valf() : -__builtin_huge_valf());
         if (!init_from_out)
             hipLaunchKernelGGL((zero_empty_kernel<T>), dim3(go), dim3(256), 0, stream, out, arg_out, nout, E);
     }

@@ -7,9 +7,11 @@
 //                                       along a dim: one sort of 64-bit keys (segment << 32 | key),
 //                                       4 + ceil(log2(segments)/8) passes, fed in memory order so ties keep position
 //   64-bit keys (i64, f64)              1-D only: 8 passes over u64 keys
-// 16-bit floats skip the passes over key bytes that are identically zero. Values are recovered from the keys.
-// -0.0 is keyed like +0.0 (torch compares them equal) and returned as +0.0; every NaN sorts last (first when
-// descending). HBM-bound: per pass hist reads the keys, scatter reads and writes keys + values.
+// 16-bit floats skip the passes over key bytes that are identically zero. Values are recovered from the keys, except
+// where the key does not determine the bits: -0.0 is keyed like +0.0 (torch compares them equal) and every NaN gets the
+// top key (NaNs sort last; first when descending) — those elements are re-read from the input at their source position,
+// so `values` is bit for bit `input.gather(dim, indices)` as with torch.sort (signed zeros, NaN signs and payloads kept).
+// HBM-bound: per pass hist reads the keys, scatter reads and writes keys + values.
 #include "common.h"
 #include "sort_engine.h"
 
@@ -40,17 +42,23 @@ __device__ inline double key_f64(uint64_t k) {
 
 template <int ST> struct SortType;
 template <> struct SortType<ST_F32> { using T = float; using Key = uint32_t;
-    __device__ static Key key(T x) { return f32_key(x); } __device__ static T val(Key k) { return key_f32(k); } };
+    __device__ static Key key(T x) { return f32_key(x); } __device__ static T val(Key k) { return key_f32(k); }
+    __device__ static bool special(Key k) { return k == 0x80000000u || k == 0xffffffffu; } };
 template <> struct SortType<ST_F16> { using T = __half; using Key = uint32_t;
-    __device__ static Key key(T x) { return f32_key(__half2float(x)); } __device__ static T val(Key k) { return __float2half(key_f32(k)); } };
+    __device__ static Key key(T x) { return f32_key(__half2float(x)); } __device__ static T val(Key k) { return __float2half(key_f32(k)); }
+    __device__ static bool special(Key k) { return k == 0x80000000u || k == 0xffffffffu; } };
 template <> struct SortType<ST_BF16> { using T = __hip_bfloat16; using Key = uint32_t;
-    __device__ static Key key(T x) { return f32_key(__bfloat162float(x)); } __device__ static T val(Key k) { return __float2bfloat16(key_f32(k)); } };
+    __device__ static Key key(T x) { return f32_key(__bfloat162float(x)); } __device__ static T val(Key k) { return __float2bfloat16(key_f32(k)); }
+    __device__ static bool special(Key k) { return k == 0x80000000u || k == 0xffffffffu; } };
 template <> struct SortType<ST_I32> { using T = int32_t; using Key = uint32_t;
-    __device__ static Key key(T x) { return (uint32_t)x ^ 0x80000000u; } __device__ static T val(Key k) { return (int32_t)(k ^ 0x80000000u); } };
+    __device__ static Key key(T x) { return (uint32_t)x ^ 0x80000000u; } __device__ static T val(Key k) { return (int32_t)(k ^ 0x80000000u); }
+    __device__ static bool special(Key) { return false; } };
 template <> struct SortType<ST_I64> { using T = int64_t; using Key = uint64_t;
-    __device__ static Key key(T x) { return (uint64_t)x ^ 0x8000000000000000ull; } __device__ static T val(Key k) { return (int64_t)(k ^ 0x8000000000000000ull); } };
+    __device__ static Key key(T x) { return (uint64_t)x ^ 0x8000000000000000ull; } __device__ static T val(Key k) { return (int64_t)(k ^ 0x8000000000000000ull); }
+    __device__ static bool special(Key) { return false; } };
 template <> struct SortType<ST_F64> { using T = double; using Key = uint64_t;
-    __device__ static Key key(T x) { return f64_key(x); } __device__ static T val(Key k) { return key_f64(k); } };
+    __device__ static Key key(T x) { return f64_key(x); } __device__ static T val(Key k) { return key_f64(k); }
+    __device__ static bool special(Key k) { return k == 0x8000000000000000ull || k == ~0ull; } };
 
 #define GRID_STRIDE(i, total) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
@@ -78,18 +86,22 @@ __global__ void build_seg_keys_kernel(const typename SortType<ST>::T* __restrict
 }
 template <int ST>
 __global__ void finish_flat_kernel(const typename SortType<ST>::Key* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                   const typename SortType<ST>::T* __restrict__ in,
                                    typename SortType<ST>::T* __restrict__ values, int64_t* __restrict__ indices, int64_t n,
                                    int descending) {
     GRID_STRIDE(p, n) {
         typename SortType<ST>::Key k = keys[p];
         if (descending) k = (typename SortType<ST>::Key)~k;
-        values[p] = SortType<ST>::val(k);
-        indices[p] = (int64_t)vals[p];
+        const uint32_t e = vals[p];
+        // zeros and NaNs: the key does not fix the bits. Equal keys keep position order, so these re-reads ascend.
+        values[p] = SortType<ST>::special(k) ? in[e] : SortType<ST>::val(k);
+        indices[p] = (int64_t)e;
     }
 }
 // sorted position p = seg*E + r  ->  output element [b, r, k]; source position e from the linear index.
 template <int ST>
 __global__ void finish_seg_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                  const typename SortType<ST>::T* __restrict__ in,
                                   typename SortType<ST>::T* __restrict__ values, int64_t* __restrict__ indices, int64_t B,
                                   int64_t E, int64_t K, int descending) {
     GRID_STRIDE(p, B * E * K) {
@@ -98,8 +110,9 @@ __global__ void finish_seg_kernel(const uint64_t* __restrict__ keys, const uint3
         const int64_t o = (b * E + r) * K + k;
         uint32_t key = (uint32_t)keys[p];
         if (descending) key = ~key;
-        values[o] = SortType<ST>::val(key);
-        indices[o] = ((int64_t)vals[p] / K) % E;
+        const uint32_t lin = vals[p];   // linear position of the element in `in`
+        values[o] = SortType<ST>::special(key) ? in[lin] : SortType<ST>::val(key);
+        indices[o] = ((int64_t)lin / K) % E;
     }
 }
 
@@ -170,7 +183,7 @@ int sort_typed(const void* input, void* values, int64_t* indices, int64_t B, int
                            (uint64_t*)w.keys_b, n, descending);
         uint64_t* sk; uint32_t* sv;
         if (int rc = sort_u64(w, n, 0, 64, 0, 0, stream, &sk, &sv)) return rc;
-        hipLaunchKernelGGL((finish_flat_kernel<ST>), dim3(grid_for(n)), dim3(256), 0, stream, sk, sv, (TT*)values, indices, n, descending);
+        hipLaunchKernelGGL((finish_flat_kernel<ST>), dim3(grid_for(n)), dim3(256), 0, stream, sk, sv, (const TT*)input, (TT*)values, indices, n, descending);
         return gnnops_check_launch("sort finish");
     } else {
         if (flat) {
@@ -192,7 +205,7 @@ int sort_typed(const void* input, void* values, int64_t* indices, int64_t B, int
                 // a complemented key has ones, not zeros, in the dead low bits: still constant, still skippable
                 if (int rc = sort_u32(w, n, zero_lo, stream, &sk, &sv)) return rc;
             }
-            hipLaunchKernelGGL((finish_flat_kernel<ST>), dim3(grid_for(n)), dim3(256), 0, stream, sk, sv, (TT*)values, indices, n, descending);
+            hipLaunchKernelGGL((finish_flat_kernel<ST>), dim3(grid_for(n)), dim3(256), 0, stream, sk, sv, (const TT*)input, (TT*)values, indices, n, descending);
             return gnnops_check_launch("sort finish");
         }
         const int64_t segs = B * K;
@@ -202,7 +215,7 @@ int sort_typed(const void* input, void* values, int64_t* indices, int64_t B, int
                            (uint64_t*)w.keys_b, B, E, K, descending);
         uint64_t* sk; uint32_t* sv;
         if (int rc = sort_u64(w, n, zero_lo, 32 + 8 * ((segbits + 7) / 8), 0, 0, stream, &sk, &sv)) return rc;
-        hipLaunchKernelGGL((finish_seg_kernel<ST>), dim3(grid_for(n)), dim3(256), 0, stream, sk, sv, (TT*)values, indices, B, E, K, descending);
+        hipLaunchKernelGGL((finish_seg_kernel<ST>), dim3(grid_for(n)), dim3(256), 0, stream, sk, sv, (const TT*)input, (TT*)values, indices, B, E, K, descending);
         return gnnops_check_launch("sort finish");
     }
 }

@@ -151,8 +151,12 @@ __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restr
         for (int r = 0; r < ROUNDS; ++r) {
             const int i = wave_base + r * 64 + lane;
             if (i < E) {
-                vdst[i] = key_f32(descending ? ~key[r] : key[r]);
-                idst[i] = (int64_t)(px[r] >> 16) + off;
+                const uint32_t k = descending ? ~key[r] : key[r];
+                const uint32_t e = px[r] >> 16;
+                // a zero or a NaN: the key does not fix the bits (-0.0 keyed as +0.0, one key for all NaNs) — re-read the
+                // element (the row was just streamed: an L2 hit), so values == input.gather(indices) bit for bit
+                vdst[i] = (k == 0x80000000u || k == 0xffffffffu) ? src[e] : key_f32(k);
+                idst[i] = (int64_t)e + off;
             }
         }
     }

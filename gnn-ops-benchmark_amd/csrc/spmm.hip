@@ -15,6 +15,7 @@
 // 16-bit inputs: v*x is exact in fp32, acc in fp32, rounded once to the storage type.
 #include "common.h"
 #include "hub.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -157,6 +158,12 @@ int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const
         const int64_t vecs = D / VEC;
         int gshift = 0;
         while ((1 << gshift) < vecs && gshift < 6) ++gshift;
+        // A/B switch for tools/time_spmm.py: narrower lane groups = column slices of the dense operand, swept slice by slice
+        // (items are chunk-major), so that the gathered slice of `mat` can stay in the Infinity Cache
+        if (const char* gs = getenv("GNNOPS_SPMM_GSHIFT")) {
+            const int g = atoi(gs);
+            if (g >= 0 && g < gshift) gshift = g;
+        }
         const int kchunks = (int)gnnops_cdiv(vecs, (int64_t)1 << gshift);
         const int grid = gnnops_grid_cap(gnnops_cdiv((int64_t)kchunks * M, 256 >> gshift), 256 * 64);
         // a dense operand far beyond the 256 MiB Infinity Cache is streamed nontemporally (its rows would only evict

@@ -60,6 +60,8 @@ SIGNATURES = {
     "gnnops_spspmm_expand": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp]),
     "gnnops_rowptr_workspace_bytes": (_sz, [_i64]),
     "gnnops_rowptr_from_sorted": (_ci, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "gnnops_rowptr_expand": (_ci, [_vp, _i64, _i64, _vp, _vp]),
+    "gnnops_sddmm": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _ci, _vp]),
     "gnnops_segment_composite": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp]),
     "gnnops_segment_composite_hubs": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp, _sz, _vp]),
     "gnnops_addmm_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -32,6 +32,21 @@ def install():
     lib = torch.library.Library("aten", "IMPL")
     routed = set()
 
+    def below_autograd(fn):
+        """A kernel registered on the CUDA / SparseCUDA key runs BELOW PyTorch's Autograd key: the stock derivative
+        formulas of the ATen op have already been recorded, so the raw kernels are what must run here (their own
+        "operand requires grad" refusal does not apply)."""
+        def kernel(*args, **kwargs):
+            with torch.no_grad():
+                return fn(*args, **kwargs)
+        kernel.__name__ = fn.__name__
+        return kernel
+
+    _impl = lib.impl
+
+    def impl(name, fn, key):
+        _impl(name, below_autograd(fn), key)
+
     def index_select(self, dim, index):
         return ops.index_select(self, dim, index)
 
@@ -84,7 +99,7 @@ def install():
 
         return sp.coalesce_sparse_tensor(self)
 
-    lib.impl("scatter_.reduce", scatter_reduce_, "CUDA")
+    impl("scatter_.reduce", scatter_reduce_, "CUDA")
     routed.update({"scatter_.reduce"})
     # sparse COO operands dispatch on the SparseCUDA key (torch.sparse.mm, Tensor.coalesce()); optional: a build
     # that refuses these registrations keeps its stock kernels and gnnops.sparse_mm / coalesce_sparse_tensor stay
@@ -101,20 +116,20 @@ def install():
     for name, fn in (("_sparse_mm", sparse_mm), ("addmm", sparse_addmm), ("_sparse_sparse_matmul", sparse_mm),
                      ("_coalesce", sparse_coalesce)):
         try:
-            lib.impl(name, fn, "SparseCUDA")
+            impl(name, fn, "SparseCUDA")
             routed.add(name + "@SparseCUDA")
         except Exception:  # pragma: no cover - depends on the torch build
             pass
-    lib.impl("sort.stable", sort_stable, "CUDA")
-    lib.impl("sort", sort_default, "CUDA")
-    lib.impl("addmm", addmm, "CUDA")
-    lib.impl("mm", mm, "CUDA")
-    lib.impl("index_select", index_select, "CUDA")
-    lib.impl("gather", gather, "CUDA")
-    lib.impl("index_add_", index_add_, "CUDA")
-    lib.impl("index_add", index_add, "CUDA")
-    lib.impl("scatter_add_", scatter_add_, "CUDA")
-    lib.impl("scatter_add", scatter_add, "CUDA")
+    impl("sort.stable", sort_stable, "CUDA")
+    impl("sort", sort_default, "CUDA")
+    impl("addmm", addmm, "CUDA")
+    impl("mm", mm, "CUDA")
+    impl("index_select", index_select, "CUDA")
+    impl("gather", gather, "CUDA")
+    impl("index_add_", index_add_, "CUDA")
+    impl("index_add", index_add, "CUDA")
+    impl("scatter_add_", scatter_add_, "CUDA")
+    impl("scatter_add", scatter_add, "CUDA")
     _library = lib
     global routed_ops
     routed_ops = routed | {"index_select", "gather", "index_add_", "index_add", "scatter_add_", "scatter_add", "sort",

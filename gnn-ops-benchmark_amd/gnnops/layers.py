@@ -7,7 +7,7 @@ row once — the [E, D] message tensor never exists.
 """
 import torch
 
-from . import ops, sparse
+from . import autograd, sparse
 
 
 def propagate_sum(x, edge_index, num_nodes=None):
@@ -21,17 +21,17 @@ def propagate_mean(x, edge_index, num_nodes=None):
     if num_nodes is None:
         num_nodes = x.size(0)
     s = propagate_sum(x, edge_index, num_nodes)
-    deg = ops.scatter(torch.ones(edge_index.size(1), 1, dtype=x.dtype, device=x.device), edge_index[1], 0, None, num_nodes, "sum")
+    deg = autograd.scatter(torch.ones(edge_index.size(1), 1, dtype=x.dtype, device=x.device), edge_index[1], 0, None, num_nodes, "sum")
     return s / deg.clamp_(min=1)
 
 
 def gin_conv(x, edge_index, weight, bias=None, eps=0.0):
     """GIN layer with a single linear map: ((1 + eps) * x + sum_j x_j) @ weight + bias  (weight [D_in, D_out])."""
     h = propagate_sum(x, edge_index) + (1.0 + eps) * x
-    return ops.addmm(bias, h, weight) if bias is not None else ops.matmul(h, weight)
+    return autograd.addmm(bias, h, weight) if bias is not None else autograd.matmul(h, weight)
 
 
 def sage_conv(x, edge_index, weight_self, weight_neigh, bias=None):
     """GraphSAGE (mean aggregator): x @ W_self + mean_j x_j @ W_neigh + bias."""
-    out = ops.matmul(x, weight_self)
-    return ops.addmm(out if bias is None else out + bias, propagate_mean(x, edge_index), weight_neigh)
+    out = autograd.matmul(x, weight_self)
+    return autograd.addmm(out if bias is None else out + bias, propagate_mean(x, edge_index), weight_neigh)

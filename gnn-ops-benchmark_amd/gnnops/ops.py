@@ -38,6 +38,19 @@ def _require_gpu(*tensors):
             )
 
 
+def _refuse_grad(what, *tensors):
+    """The raw ops fill `torch.empty` outputs through ctypes: autograd does not see them. Called with a tensor that
+    requires grad (outside a torch.autograd.Function, where grad mode is off) they would hand back a result cut off from
+    the graph — refuse instead. The differentiable entry points are gnnops.autograd.* (what `gnnops.scatter` etc. and
+    the torch_scatter / torch_sparse shims export)."""
+    if torch.is_grad_enabled():
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.requires_grad:
+                raise NotImplementedError(
+                    f"gnnops.ops.{what}: an operand requires grad but this raw entry point has no backward; call the "
+                    f"gnnops.{what.split('(')[0]} / torch_scatter / torch_sparse name (autograd-aware) or detach the operand")
+
+
 def _dtype_code(t, what):
     try:
         return _DT[t.dtype]
@@ -143,19 +156,26 @@ def clear_plan_cache():
     _plan_cache.clear()
 
 
+def _version_of(t):
+    """Version counter of a tensor, or None when it has none: tensors created under torch.inference_mode() do not
+    track in-place writes (``t._version`` raises), so nothing derived from their contents may be cached."""
+    return None if t.is_inference() else t._version
+
+
 def get_plan(index, N, owner=None, tag=0):
     """Plan for ``index`` (cached per tensor object + version counter while the cache is enabled).
 
     ``owner`` (default: ``index`` itself) is the tensor object the cache entry is tied to: a row of a COO
     ``edge_index`` is a fresh view object on every call, so its plan is cached under the [2, E] parent, with ``tag``
-    telling the rows apart."""
+    telling the rows apart. An index created under ``torch.inference_mode()`` has no version counter, so an in-place
+    write to it could not be noticed: its plan is rebuilt on every call (pass an explicit ``Plan`` to reuse one)."""
     if isinstance(index, Plan):
         if index.N != N:
             raise ValueError(f"Plan was built for N={index.N}, op needs N={N}")
         return index
-    if not _plan_cache_enabled:
-        return Plan(index, N)
     owner = index if owner is None else owner
+    if not _plan_cache_enabled or owner.is_inference():
+        return Plan(index, N)
     key = (id(owner), tag)
     hit = _plan_cache.get(key)
     if hit is not None:
@@ -220,6 +240,7 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
     rcode = REDUCE_CODE[reduce]
     is_plan = isinstance(index, Plan)
     _require_gpu(src, out, None if is_plan else index)
+    _refuse_grad("scatter", src, out)
     dt = _dtype_code(src, "scatter")
     dim = _norm_dim(dim, src.dim(), "scatter")
     src = src.contiguous()
@@ -371,6 +392,7 @@ def index_select(input, dim, index, plan=None):
     input.size(dim), given or built here when the heuristic above says so): every input row is read once
     and stored to all output rows that select it — N*row reads instead of E*row."""
     _require_gpu(input, index)
+    _refuse_grad("index_select", input)
     if index.dtype == torch.int32:  # ATen takes IntTensor indices here; the kernels read int64
         index = index.long()
     _check_index(index, "index_select")
@@ -420,6 +442,7 @@ def index_select(input, dim, index, plan=None):
 def gather(input, dim, index):
     """torch.gather(input, dim, index) for index spanning input outside ``dim``."""
     _require_gpu(input, index)
+    _refuse_grad("gather", input)
     _check_index(index, "gather")
     if index.dim() != input.dim():
         raise RuntimeError("gather(): Index tensor must have the same number of dimensions as input tensor")
@@ -471,6 +494,7 @@ def index_select_sum(input, dim, index):
     """fp32 value of ``torch.index_select(input, dim, index).sum()`` without materialising the gather
     (benchmark_fused_index_select_reduce.py:12-20). Returns a 0-dim float32 device tensor."""
     _require_gpu(input, index)
+    _refuse_grad("index_select_sum", input)
     _check_index(index, "index_select_sum")
     dt = _dtype_code(input, "index_select_sum")
     dim = _norm_dim(dim, input.dim(), "index_select_sum")
@@ -493,6 +517,7 @@ def index_add_select_sum(input, dim, index, other):
     (benchmark_fused_index_add_reduce.py:12-20) in one pass; nothing of input's size is materialised."""
     is_plan = isinstance(index, Plan)
     _require_gpu(input, other, None if is_plan else index)
+    _refuse_grad("index_add_select_sum", input, other)
     dt = _dtype_code(input, "index_add_select_sum")
     if other.dtype != input.dtype:
         raise RuntimeError("index_add_select_sum: input and other must have the same dtype")
@@ -528,6 +553,7 @@ def addmm(input, mat1, mat2, *, beta=1, alpha=1):
     if beta != 1 or alpha != 1:
         raise NotImplementedError("gnnops.addmm: beta and alpha must be 1")
     _require_gpu(input, mat1, mat2)
+    _refuse_grad("addmm", input, mat1, mat2)
     if mat1.dim() != 2 or mat2.dim() != 2:
         raise RuntimeError("addmm: mat1 and mat2 must be matrices")
     if mat1.size(1) != mat2.size(0):

@@ -46,17 +46,40 @@ def _reduce_over(plan, src, dim, reduce, want_arg):
     return (out, arg) if want_arg else out
 
 
-def segment_csr(src, indptr, out=None, reduce="sum"):
-    """torch_scatter.segment_csr(src, indptr, out, reduce) for a 1-D indptr: segments along dim 0... the last
-    dimension of indptr, i.e. dim = indptr.dim() - 1 = 0."""
-    if out is not None:
-        raise NotImplementedError("gnnops.segment_csr: out= is not supported")
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _segment_csr_raw(src, indptr, reduce="sum"):
     _require_gpu(src, indptr)
     if indptr.dim() != 1:
         raise NotImplementedError("gnnops.segment_csr: indptr must be 1-D")
     src = src.contiguous()
     plan = _CSR(_as_int32_rowptr(indptr), src.size(0))
     return _reduce_over(plan, src, 0, reduce, reduce in ("min", "max"))
+
+
+def segment_csr(src, indptr, out=None, reduce="sum"):
+    """torch_scatter.segment_csr(src, indptr, out, reduce) for a 1-D indptr: segments along dim 0... the last
+    dimension of indptr, i.e. dim = indptr.dim() - 1 = 0. Differentiable in src (gnnops/autograd.py)."""
+    if out is not None:
+        raise NotImplementedError("gnnops.segment_csr: out= is not supported")
+    if _needs_grad(src):
+        from . import autograd
+
+        return autograd.segment_csr(src, indptr, reduce)
+    return _segment_csr_raw(src, indptr, reduce)
+
+
+def expand_rowptr(indptr, E):
+    """int64 [E]: the segment of the CSR pointer that holds each position (N = indptr.numel() - 1 where none does)."""
+    _require_gpu(indptr)
+    rowptr = _as_int32_rowptr(indptr)
+    index = torch.empty(E, dtype=torch.int64, device=indptr.device)
+    with torch.cuda.device(indptr.device):
+        check(_lib.load().gnnops_rowptr_expand(rowptr.data_ptr(), rowptr.numel() - 1, E, index.data_ptr(), _stream()),
+              "rowptr_expand")
+    return index
 
 
 def rowptr_from_sorted(index, N):
@@ -75,9 +98,18 @@ def rowptr_from_sorted(index, N):
 
 
 def segment_coo(src, index, out=None, dim_size=None, reduce="sum"):
-    """torch_scatter.segment_coo(src, index, out, dim_size, reduce): index 1-D, SORTED, along dim 0."""
+    """torch_scatter.segment_coo(src, index, out, dim_size, reduce): index 1-D, SORTED, along dim 0.
+    Differentiable in src (gnnops/autograd.py)."""
     if out is not None:
         raise NotImplementedError("gnnops.segment_coo: out= is not supported")
+    if _needs_grad(src):
+        from . import autograd
+
+        return autograd.segment_coo(src, index, dim_size, reduce)
+    return _segment_coo_raw(src, index, dim_size, reduce)
+
+
+def _segment_coo_raw(src, index, dim_size=None, reduce="sum"):
     _require_gpu(src, index)
     if index.dim() != 1:
         raise NotImplementedError("gnnops.segment_coo: index must be 1-D")
@@ -90,17 +122,35 @@ def segment_coo(src, index, out=None, dim_size=None, reduce="sum"):
 
 
 def gather_csr(src, indptr, out=None):
-    """torch_scatter.gather_csr: out[e] = src[segment containing e]."""
+    """torch_scatter.gather_csr: out[e] = src[segment containing e], e in [0, indptr[-1]) — reading indptr[-1] back
+    sizes the output, as in the upstream op. Differentiable in src."""
+    if out is not None:
+        raise NotImplementedError("gnnops.gather_csr: out= is not supported")
     _require_gpu(src, indptr)
+    if indptr.dim() != 1:
+        raise NotImplementedError("gnnops.gather_csr: indptr must be 1-D")
+    E = int(indptr[-1].item()) if indptr.numel() else 0
+    if _needs_grad(src):
+        from . import autograd
+
+        return autograd.gather_csr(src, indptr, E)
     from .ops import index_select
 
-    counts = (indptr[1:] - indptr[:-1]).to(torch.int64)
-    index = torch.repeat_interleave(torch.arange(counts.numel(), device=src.device), counts)
+    # positions below indptr[0] belong to no segment (index == N): they read an appended zero row
+    index = expand_rowptr(indptr, E)
+    if int(indptr[0].item()) > 0:
+        src = torch.cat([src, src.new_zeros((1,) + tuple(src.shape[1:]))])
     return index_select(src, 0, index)
 
 
 def gather_coo(src, index, out=None):
-    """torch_scatter.gather_coo: out[e] = src[index[e]] along dim 0."""
+    """torch_scatter.gather_coo: out[e] = src[index[e]] along dim 0. Differentiable in src."""
+    if out is not None:
+        raise NotImplementedError("gnnops.gather_coo: out= is not supported")
+    if _needs_grad(src):
+        from . import autograd
+
+        return autograd.gather_coo(src, index)
     from .ops import index_select
 
     return index_select(src, 0, index)

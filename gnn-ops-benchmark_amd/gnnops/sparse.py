@@ -18,12 +18,27 @@ def _coo_rows_cols(index, what):
     return index, index[0], index[1]
 
 
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def spmm(index, value, m, n, matrix):
-    """torch_sparse.spmm(index, value, m, n, matrix): (m x n sparse) @ (n x D dense) -> m x D."""
+    """torch_sparse.spmm(index, value, m, n, matrix): (m x n sparse) @ (n x D dense) -> m x D.
+    Differentiable in value and matrix (gnnops/autograd.py)."""
+    if _needs_grad(value, matrix):
+        from . import autograd
+
+        if matrix.dim() == 1:
+            return autograd.spmm(index, value, m, n, matrix.unsqueeze(-1)).squeeze(-1)
+        return autograd.spmm(index, value, m, n, matrix)
+    return _spmm_raw(index, value, m, n, matrix)
+
+
+def _spmm_raw(index, value, m, n, matrix):
     _require_gpu(index, value, matrix)
     index, row, col = _coo_rows_cols(index, "spmm")
     if matrix.dim() == 1:
-        return spmm(index, value, m, n, matrix.unsqueeze(-1)).squeeze(-1)
+        return _spmm_raw(index, value, m, n, matrix.unsqueeze(-1)).squeeze(-1)
     if matrix.dim() != 2:
         raise NotImplementedError("gnnops.spmm: matrix must be 1-D or 2-D")
     if matrix.size(0) != n:
@@ -33,24 +48,53 @@ def spmm(index, value, m, n, matrix):
         raise RuntimeError("spmm: value and matrix must have the same dtype")
     matrix = matrix.contiguous()
     plan = get_plan(row, m, owner=index, tag=0)  # COO -> CSR view (rowptr, perm), stable; cached under the [2, nnz] tensor
-    return _spmm_launch(plan.rowptr, plan.perm, col, value, matrix, m, dt, plan)
+    return _spmm_launch(plan.rowptr, plan.perm, col, value, matrix, m, dt, plan, owner=index, tag=1)
 
 
 def spmm_t(index, value, m, n, matrix):
     """(n x m)^T-side product without materialising the transposed index: out[i] = sum over entries (j, i) of
     value * matrix[j], i.e. rows of the result follow index[1] and the gathered rows follow index[0]. This is
-    message passing over a PyG-style edge_index = (source, destination): out [n, D], matrix [m, D]."""
+    message passing over a PyG-style edge_index = (source, destination): out [n, D], matrix [m, D].
+    Differentiable in value and matrix."""
+    if _needs_grad(value, matrix):
+        from . import autograd
+
+        return autograd.spmm_t(index, value, m, n, matrix)
+    return _spmm_t_raw(index, value, m, n, matrix)
+
+
+def _spmm_t_raw(index, value, m, n, matrix):
     _require_gpu(index, value, matrix)
     index, src_rows, dst_rows = _coo_rows_cols(index, "spmm_t")
     if matrix.dim() != 2 or matrix.size(0) != m:
         raise RuntimeError("spmm_t: matrix must be [m, D]")
     dt = _dtype_code(matrix, "spmm_t")
     plan = get_plan(dst_rows, n, owner=index, tag=1)
-    return _spmm_launch(plan.rowptr, plan.perm, src_rows, value, matrix.contiguous(), n, dt, plan)
+    return _spmm_launch(plan.rowptr, plan.perm, src_rows, value, matrix.contiguous(), n, dt, plan, owner=index, tag=0)
+
+
+def sddmm(rows_a, rows_b, a, b):
+    """out[k] = <a[rows_a[k], :], b[rows_b[k], :]> (sampled dense-dense product; the value gradient of spmm)."""
+    _require_gpu(rows_a, rows_b, a, b)
+    _check_index(rows_a, "sddmm")
+    _check_index(rows_b, "sddmm")
+    if a.dim() != 2 or b.dim() != 2 or a.size(1) != b.size(1) or a.dtype != b.dtype:
+        raise RuntimeError("sddmm: a and b must be 2-D with equal row length and dtype")
+    if rows_a.numel() != rows_b.numel():
+        raise RuntimeError("sddmm: rows_a and rows_b must have the same length")
+    dt = _dtype_code(a, "sddmm")
+    rows_a, rows_b, a, b = rows_a.contiguous(), rows_b.contiguous(), a.contiguous(), b.contiguous()
+    out = torch.empty(rows_a.numel(), dtype=a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        check(_lib.load().gnnops_sddmm(rows_a.data_ptr(), rows_b.data_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                       rows_a.numel(), a.size(1), dt, _stream()), "sddmm")
+    return out
 
 
 def spmm_csr(rowptr, col, value, matrix):
     """CSR x dense (BASELINE config 3's layout): rowptr int32/int64 [M+1], col int64 [nnz], value [nnz] or None."""
+    if _needs_grad(value, matrix):
+        raise NotImplementedError("gnnops.spmm_csr has no backward: use gnnops.spmm (COO) inside a training graph, or detach")
     _require_gpu(rowptr, col, value, matrix)
     _check_index(col, "spmm_csr")
     if rowptr.dtype == torch.int64:
@@ -68,27 +112,39 @@ def _permute(t, perm, n):
     return out
 
 
-def _csr_arrays(plan, col, value):
-    """CSR column ids (and values) of a COO operand in plan order, cached on the plan per (col, value) tensor version."""
-    key = (id(col), col._version, None if value is None else (id(value), value._version))
-    cached = getattr(plan, "_csr", None)
-    if cached is not None and cached[0] == key and cached[1]() is col and (value is None or cached[2]() is value):
-        return cached[3], cached[4]
+def _csr_arrays(plan, col, value, owner=None, tag=0):
+    """CSR column ids (and values) of a COO operand in plan order, kept on the plan.
+
+    The entry is keyed on the tensor OBJECTS that own the data — ``owner`` is the [2, nnz] index tensor the caller
+    passed (``col`` is a row view of it and a fresh object on every call, so it cannot be the key), ``tag`` says which of
+    its rows is the column — plus their version counters; weak references guard against a recycled ``id``. Tensors
+    without a version counter (created under torch.inference_mode()) are never cached."""
+    from .ops import _version_of
+
+    owner = col if owner is None else owner
+    cacheable = _version_of(owner) is not None and (value is None or _version_of(value) is not None)
+    key = None
+    if cacheable:
+        key = (id(owner), tag, owner._version, None if value is None else (id(value), value._version))
+        cached = getattr(plan, "_csr", None)
+        if cached is not None and cached[0] == key and cached[1]() is owner and (value is None or cached[2]() is value):
+            return cached[3], cached[4]
     n = col.numel()
     col_csr = _permute(col, plan.perm, n)
     val_csr = _permute(value.contiguous(), plan.perm, n) if value is not None else None
-    import weakref
+    if cacheable:
+        import weakref
 
-    try:
-        plan._csr = (key, weakref.ref(col), weakref.ref(value) if value is not None else None, col_csr, val_csr)
-    except AttributeError:
-        pass
+        try:
+            plan._csr = (key, weakref.ref(owner), weakref.ref(value) if value is not None else None, col_csr, val_csr)
+        except AttributeError:
+            pass
     return col_csr, val_csr
 
 
-def _spmm_launch(rowptr, perm, col, value, matrix, m, dt, plan=None):
+def _spmm_launch(rowptr, perm, col, value, matrix, m, dt, plan=None, owner=None, tag=0):
     if perm is not None and plan is not None and col.numel() > 0:
-        col, value = _csr_arrays(plan, col, value)  # stream CSR arrays instead of chasing perm -> col per nonzero
+        col, value = _csr_arrays(plan, col, value, owner, tag)  # stream CSR arrays instead of chasing perm -> col per nonzero
         perm = None
     D = matrix.size(1)
     out = torch.empty((m, D), dtype=matrix.dtype, device=matrix.device)

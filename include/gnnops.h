@@ -311,6 +311,14 @@ int gnnops_spspmm_expand(const int64_t* rowA, const int64_t* colA, const void* v
  *   mode 2 logsumexp    out[B,N,K] = max + log(sum + param)               param = eps
  *   mode 3 std          out[B,N,K] = sqrt(sum (x - mean)^2 / (cnt' + 1e-6)), param != 0: unbiased (cnt' = max(cnt-1,1))
  * ------------------------------------------------------------------------------------------- */
+/* Backward-pass pieces (gnnops/autograd.py; the rest of every backward is one of the forward entry points above):
+ *   gnnops_rowptr_expand  index[e] = n with rowptr[n] <= e < rowptr[n+1], or N where no segment holds e (E positions):
+ *                         torch_scatter.gather_csr's addressing and the gather behind segment_csr's gradient.
+ *   gnnops_sddmm          out[k] = sum_d a[rows_a[k], d] * b[rows_b[k], d]: d(value) of torch_sparse.spmm
+ *                         (benchmark_sparse_spmm.py:12-14 under autograd); fp32 accumulation, one rounding. */
+int gnnops_rowptr_expand(const int32_t* rowptr, int64_t N, int64_t E, int64_t* index, gnnops_stream_t stream);
+int gnnops_sddmm(const int64_t* rows_a, const int64_t* rows_b, const void* a, const void* b, void* out,
+                 int64_t nnz, int64_t D, int dtype, gnnops_stream_t stream);
 size_t gnnops_rowptr_workspace_bytes(int64_t N);
 int gnnops_rowptr_from_sorted(const int64_t* sorted_index, int64_t E, int64_t N, int32_t* rowptr,
                               void* workspace, size_t workspace_bytes, gnnops_stream_t stream);

@@ -206,12 +206,12 @@ def spmm(index, value, m, n, matrix, dtype=None):
 
 
 def sort(input, dim=-1):
-    """torch.sort(input, dim, stable=True) for float32: ascending, ties by position, NaN last, -0.0 == +0.0
-    (returned as +0.0, the device convention). numpy's stable argsort is the restatement."""
+    """torch.sort(input, dim, stable=True) for float32: ascending, ties by position, NaN last, -0.0 == +0.0 as keys.
+    Values are the ORIGINAL elements (values == input.gather(dim, indices) bit for bit: signed zeros and NaN payloads
+    survive), as torch.sort returns them. numpy's stable argsort is the restatement."""
     x = np.ascontiguousarray(input, dtype=np.float32)
     idx = np.argsort(x, axis=dim, kind="stable").astype(np.int64)
     vals = np.take_along_axis(x, idx, axis=dim)
-    vals = np.where(vals == 0, np.float32(0.0), vals)
     return vals, idx
 
 

@@ -147,3 +147,25 @@ def test_product_never_touches_the_oracle_or_a_cpu_fallback():
         text = open(os.path.join(ROOT, name)).read()
         first_use = text.index("from oracle import oracle")
         assert first_use > text.index(needle), f"{name}: oracle imported outside {needle}"
+
+
+def test_raw_ops_never_drop_a_gradient_silently():
+    """The guard every raw entry point runs first (gnnops/ops.py _refuse_grad): an operand that requires grad raises while
+    grad mode is on — outside a torch.autograd.Function nothing may hand back a tensor cut off from the graph — and passes
+    under no_grad (where the Functions' forward / backward run)."""
+    import torch
+
+    from gnnops import ops
+
+    t = torch.rand(4, 3, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        ops._refuse_grad("scatter", t)
+    with torch.no_grad():
+        ops._refuse_grad("scatter", t)
+    ops._refuse_grad("scatter", t.detach(), None)
+    # the package-level names are the differentiable front ends
+    import gnnops
+    from gnnops import autograd
+
+    assert gnnops.scatter is autograd.scatter and gnnops.index_select is autograd.index_select
+    assert gnnops.addmm is autograd.addmm

@@ -159,9 +159,13 @@ def test_oracle_sparse_sort_matches_golden():
     out = oracle.spmm(g["coo_index"], g["coo_value"], m, n, g["spmm_B"])
     np.testing.assert_allclose(out, g["spmm_out"], rtol=1e-5, atol=1e-6)
     assert_bits_equal(oracle.transpose_dense(g["dense_in"]), g["dense_T"], "dense transpose")
-    # sort: -0.0 and NaN conventions
-    v, i = oracle.sort(np.array([0.0, -0.0, np.nan, -1.0, 0.0], np.float32), 0)
-    assert list(i) == [3, 0, 1, 4, 2] and np.isnan(v[-1]) and not np.signbit(v[1])
+    # sort: -0.0 and NaN conventions — equal as keys, original bits returned (== torch.sort on the CPU, bit for bit)
+    x = np.array([0.0, -0.0, np.nan, -1.0, 0.0], np.float32)
+    x.view(np.uint32)[2] = 0xFFC12345   # a negative NaN with a payload
+    v, i = oracle.sort(x, 0)
+    assert list(i) == [3, 0, 1, 4, 2] and np.isnan(v[-1]) and np.signbit(v[2]) and not np.signbit(v[1])
+    tv, ti = torch.sort(torch.from_numpy(x.copy()), stable=True)
+    assert np.array_equal(v.view(np.uint32), tv.numpy().view(np.uint32)) and list(ti.numpy()) == list(i)
 
 
 def test_oracle_segment_and_composite_vs_torch_cpu():

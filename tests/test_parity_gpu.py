@@ -398,3 +398,97 @@ def test_layout_f_minmax_ties_zeros_nans(gnnops, oracle, reduce, dname):
     exp, earg = oracle.scatter(to_np(src), idx.numpy(), dim=0, out=to_np(base).copy(), reduce=reduce, dtype=dname)
     assert_bits_equal(to_np(got), exp, "with out")
     assert np.array_equal(arg.cpu().numpy(), earg)
+
+
+@pytest.mark.parametrize("dname", ["f32", "f16"])
+@pytest.mark.parametrize("reduce", ["min", "max"])
+def test_minmax_identity_only_groups_agree_across_layouts(gnnops, oracle, reduce, dname):
+    """A group whose only contributions are the reduce's identity (+inf for min, -inf for max) never improves on it: the
+    sequential loop (strict compare) leaves the group "empty" — value 0, arg = E — in EVERY form: the row kernels (plan and
+    one-shot), the packed LDS element kernel and the global-atomic fallback. The reference pins nothing here
+    (torch_scatter absent: parity unpinned); what is pinned is that all forms agree with the oracle's loop and each other."""
+    ident = float("inf") if reduce == "min" else float("-inf")
+    g = torch.Generator().manual_seed(5)
+    E, K, N = 600, 16, 50
+    src = (torch.rand(E, K, generator=g) * 4 - 2).to(TORCH_DT[dname])
+    row = torch.randint(0, N, (E,), generator=g)
+    row[row == 3] = 4                          # group 3: nothing at all
+    src[row == 5] = ident                      # group 5: only identities
+    src[(row == 6).nonzero()[:1]] = ident      # group 6: an identity among ordinary values
+    src[row == 9] = -ident                     # group 9: only the opposite infinity (an ordinary winner)
+    exp, earg = oracle.scatter(to_np(src), row.numpy(), dim=0, dim_size=N, reduce=reduce, dtype=dname)
+    assert (f32_of(exp, dname)[5] == 0).all() and (earg[5] == E).all()
+    full = row.view(-1, 1).expand(E, K).contiguous()              # layout F: same destinations, per-element index
+    results = {
+        "row index (plan / one-shot)": gnnops.scatter(src.cuda(), row.cuda(), 0, dim_size=N, reduce=reduce),
+        "full index (LDS cells)": gnnops.scatter(src.cuda(), full.cuda(), 0, dim_size=N, reduce=reduce),
+    }
+    for what, (got, arg) in results.items():
+        assert_bits_equal(to_np(got), exp, what)
+        assert np.array_equal(arg.cpu().numpy(), earg), what
+    # the global-atomic fallback (destinations that do not fit LDS strips): two rows along dim 1, N large
+    E1, N1 = 20000, 3_000_000
+    s1 = (torch.rand(2, E1, generator=g) * 4 - 2).to(TORCH_DT[dname])
+    i1 = torch.randint(0, N1, (2, E1), generator=g)
+    s1[:, :100] = ident
+    i1[:, :100] = torch.arange(100) + 17                            # 100 groups per row fed the identity (maybe plus more)
+    got, arg = gnnops.scatter(s1.cuda(), i1.cuda(), 1, dim_size=N1, reduce=reduce)
+    exp, earg = oracle.scatter(to_np(s1), i1.numpy(), dim=1, dim_size=N1, reduce=reduce, dtype=dname)
+    assert_bits_equal(to_np(got), exp, "atomic fallback")
+    assert np.array_equal(arg.cpu().numpy(), earg)
+
+
+def test_ops_inside_inference_mode(gnnops, oracle):
+    """Tensors created under torch.inference_mode() have no version counter (`_version` raises): the plan / CSR caches
+    must step aside instead of crashing (the normal GNN inference setting)."""
+    gnnops.set_plan_cache(True)
+    try:
+        with torch.inference_mode():
+            g = torch.Generator().manual_seed(9)
+            src = torch.rand(500, 32, generator=g)
+            idx = torch.randint(0, 60, (500,), generator=g)
+            d_src, d_idx = src.cuda(), idx.cuda()
+            for _ in range(2):
+                got = gnnops.scatter_add(d_src, d_idx, dim=0, dim_size=60)
+            exp = oracle.scatter(src.numpy(), idx.numpy(), dim=0, dim_size=60, reduce="sum")
+            assert_bits_equal(to_np(got), exp, "scatter_add in inference_mode")
+            coo = torch.stack([idx, torch.randint(0, 500, (500,), generator=g)])
+            val = torch.rand(500, generator=g)
+            d_coo, d_val = coo.cuda(), val.cuda()
+            for _ in range(2):
+                out = gnnops.spmm(d_coo, d_val, 60, 500, d_src)
+            assert_bits_equal(to_np(out), oracle.spmm(coo.numpy(), val.numpy(), 60, 500, src.numpy()), "spmm in inference_mode")
+            sel = gnnops.index_select(d_src, 0, d_idx)
+            assert torch.equal(sel.cpu(), src[idx])
+    finally:
+        gnnops.set_plan_cache(False)
+
+
+def test_csr_cache_hits_for_the_same_coo_tensor(gnnops):
+    """The CSR arrays of a COO operand are kept on its plan, keyed on the [2, nnz] tensor object (not on the transient row
+    view): a second spmm / spmm_t with the same tensors must not permute again."""
+    from gnnops import sparse
+
+    gnnops.set_plan_cache(True)
+    try:
+        g = torch.Generator().manual_seed(2)
+        coo = torch.stack([torch.randint(0, 70, (900,), generator=g), torch.randint(0, 80, (900,), generator=g)]).cuda()
+        val = torch.rand(900, generator=g).cuda()
+        B = torch.rand(80, 16, generator=g).cuda()
+        calls = []
+        real = sparse._permute
+        sparse._permute = lambda *a: (calls.append(1), real(*a))[1]
+        try:
+            a = gnnops.spmm(coo, val, 70, 80, B)
+            n_first = len(calls)
+            b = gnnops.spmm(coo, val, 70, 80, B)
+            assert n_first == 2 and len(calls) == 2, calls     # columns + values, once
+            assert torch.equal(a, b)
+            val.mul_(2)                                         # an in-place write bumps the version: re-materialised
+            c = gnnops.spmm(coo, val, 70, 80, B)
+            assert len(calls) == 4
+            assert torch.equal(c, a * 2)
+        finally:
+            sparse._permute = real
+    finally:
+        gnnops.set_plan_cache(False)

@@ -282,3 +282,148 @@ def test_composite_hub_groups(gnnops, oracle, mode):
         else:
             exp[n] = m + np.log(s + 1e-12)
     np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd of the segment / gather / sparse ops and the layers (no silent loss of gradients)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+def test_segment_csr_coo_backward(gnnops, reduce):
+    """d segment_csr / d src and d segment_coo / d src against torch-CPU autograd of the scatter formulation; the CSR
+    pointer here starts past 0 and stops short of E, so some positions belong to no segment (gradient 0)."""
+    import torch_scatter
+
+    src, idx, indptr = _sorted_problem(13, E=3000, N=200, K=24)
+    src = src.double().float()
+    N = indptr.numel() - 1
+    w = torch.rand(N, src.size(1), generator=torch.Generator().manual_seed(1))
+    ref = src.clone().requires_grad_(True)
+    (_ref_scatter(ref, idx, N, reduce) * w).sum().backward()
+    for form in ("csr", "coo"):
+        d = src.clone().cuda().requires_grad_(True)
+        out = (torch_scatter.segment_csr(d, indptr.cuda(), reduce=reduce) if form == "csr"
+               else torch_scatter.segment_coo(d, idx.cuda(), dim_size=N, reduce=reduce))
+        out = out[0] if isinstance(out, tuple) else out
+        assert out.grad_fn is not None
+        (out * w.cuda()).sum().backward()
+        if reduce == "mean":
+            np.testing.assert_allclose(d.grad.cpu().numpy(), ref.grad.numpy(), rtol=1e-6, atol=1e-7)
+        else:
+            assert torch.equal(d.grad.cpu(), ref.grad), (form, reduce)
+    # a pointer that covers only positions [40, 2900): the rest of src gets a zero gradient
+    part = indptr.clamp(min=40, max=2900)
+    d = src.clone().cuda().requires_grad_(True)
+    out = torch_scatter.segment_csr(d, part.cuda(), reduce="sum")
+    (out * w.cuda()).sum().backward()
+    seg = torch.searchsorted(part[1:], torch.arange(3000), right=True)
+    pos = torch.arange(3000)
+    exp = torch.where(((pos >= int(part[0])) & (pos < int(part[-1]))).view(-1, 1), w[seg.clamp(max=N - 1)], torch.zeros(()))
+    assert torch.equal(d.grad.cpu(), exp)
+
+
+def test_gather_csr_coo_forward_backward(gnnops):
+    import torch_scatter
+
+    src, idx, indptr = _sorted_problem(5, E=2500, N=180, K=16)
+    N = indptr.numel() - 1
+    x = torch.rand(N, 16, generator=torch.Generator().manual_seed(2))
+    wt = torch.rand(2500, 16, generator=torch.Generator().manual_seed(3))
+    ref = x.clone().requires_grad_(True)
+    (ref[idx] * wt).sum().backward()
+    for form in ("csr", "coo"):
+        d = x.clone().cuda().requires_grad_(True)
+        out = torch_scatter.gather_csr(d, indptr.cuda()) if form == "csr" else torch_scatter.gather_coo(d, idx.cuda())
+        assert torch.equal(out.detach().cpu(), x[idx]), form
+        (out * wt.cuda()).sum().backward()
+        np.testing.assert_allclose(d.grad.cpu().numpy(), ref.grad.numpy(), rtol=1e-6, atol=1e-6)
+    assert torch.equal(torch_scatter.gather_csr(x.cuda(), indptr.cuda()).cpu(), x[idx])   # no-grad form
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+def test_sddmm_vs_oracle_formula(gnnops, dname):
+    g = torch.Generator().manual_seed(4)
+    for D in (64, 24, 7, 300):
+        a = (torch.rand(90, D, generator=g) * 2 - 1).to(TORCH_DT[dname])
+        b = (torch.rand(70, D, generator=g) * 2 - 1).to(TORCH_DT[dname])
+        ra, rb = torch.randint(0, 90, (800,), generator=g), torch.randint(0, 70, (800,), generator=g)
+        got = gnnops.sddmm(ra.cuda(), rb.cuda(), a.cuda(), b.cuda()).float().cpu()
+        exp = (a[ra].double() * b[rb].double()).sum(1)
+        tol = 2.0 ** -8 if dname == "bf16" else 1e-5
+        assert float(((got.double() - exp).abs() / (a[ra].double().abs() * b[rb].double().abs()).sum(1)).max()) <= tol
+
+
+def test_spmm_backward_matrix_and_value(gnnops):
+    """torch_sparse.spmm under autograd: d matrix = A^T g (the transposed row-split launch), d value = per-nonzero dot
+    (gnnops_sddmm) — against torch-CPU autograd of the dense formulation; spmm_t likewise."""
+    import torch_sparse
+
+    g = torch.Generator().manual_seed(6)
+    m, n, D, nnz = 120, 90, 40, 1500
+    idx = torch.stack([torch.randint(0, m, (nnz,), generator=g), torch.randint(0, n, (nnz,), generator=g)])
+    val = torch.rand(nnz, generator=g) * 2 - 1
+    B = torch.rand(n, D, generator=g) * 2 - 1
+    w = torch.rand(m, D, generator=g)
+    rv, rB = val.clone().requires_grad_(True), B.clone().requires_grad_(True)
+    (torch.zeros(m, D).index_add(0, idx[0], rB[idx[1]] * rv.unsqueeze(1)) * w).sum().backward()
+    dv, dB = val.clone().cuda().requires_grad_(True), B.clone().cuda().requires_grad_(True)
+    out = torch_sparse.spmm(idx.cuda(), dv, m, n, dB)
+    assert out.grad_fn is not None
+    (out * w.cuda()).sum().backward()
+    np.testing.assert_allclose(dB.grad.cpu().numpy(), rB.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dv.grad.cpu().numpy(), rv.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # transposed form (message passing over edge_index = (source, destination)), value = None
+    x = torch.rand(m, D, generator=g)
+    wt = torch.rand(n, D, generator=g)
+    rx = x.clone().requires_grad_(True)
+    (torch.zeros(n, D).index_add(0, idx[1], rx[idx[0]]) * wt).sum().backward()
+    dx = x.clone().cuda().requires_grad_(True)
+    (gnnops.spmm_t(idx.cuda(), None, m, n, dx) * wt.cuda()).sum().backward()
+    np.testing.assert_allclose(dx.grad.cpu().numpy(), rx.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_gin_layer_trains(gnnops):
+    """layers.gin_conv inside a training graph: gradients of x, weight and bias against the torch-CPU formulation
+    (bf16 weights would hide errors: fp32 operands through the fp32 MFMA GEMM, 1e-4)."""
+    from gnnops import layers
+
+    g = torch.Generator().manual_seed(7)
+    Nn, E, Din, Dout = 300, 2000, 64, 48
+    x = torch.rand(Nn, Din, generator=g) - 0.5
+    ei = torch.stack([torch.randint(0, Nn, (E,), generator=g), torch.randint(0, Nn, (E,), generator=g)])
+    W = torch.rand(Din, Dout, generator=g) - 0.5
+    b = torch.rand(Dout, generator=g)
+    rx, rW, rb = (t.clone().requires_grad_(True) for t in (x, W, b))
+    h = torch.zeros(Nn, Din).index_add(0, ei[1], rx[ei[0]]) + rx
+    ((h @ rW + rb) ** 2).sum().backward()
+    dx, dW, db = (t.clone().cuda().requires_grad_(True) for t in (x, W, b))
+    out = layers.gin_conv(dx, ei.cuda(), dW, db)
+    (out ** 2).sum().backward()
+    for got, ref in ((dx, rx), (dW, rW), (db, rb)):
+        scale = float(ref.grad.abs().max())
+        assert float((got.grad.cpu() - ref.grad).abs().max()) <= 1e-4 * scale
+
+
+def test_raw_ops_refuse_operands_that_require_grad(gnnops):
+    """No silent loss of gradients: the raw (ctypes) entry points raise when handed a tensor that requires grad, and so do
+    the forms without a backward (out=, a Plan as index, spmm_csr); under no_grad everything runs."""
+    from gnnops import ops
+
+    src = torch.rand(50, 8).cuda().requires_grad_(True)
+    idx = torch.randint(0, 10, (50,)).cuda()
+    with pytest.raises(NotImplementedError):
+        ops.scatter(src, idx, 0, dim_size=10)
+    with pytest.raises(NotImplementedError):
+        ops.index_select(src, 0, idx)
+    with pytest.raises(NotImplementedError):
+        gnnops.scatter(src, idx, 0, out=torch.zeros(10, 8).cuda())
+    with pytest.raises(NotImplementedError):
+        gnnops.scatter(src, gnnops.Plan(idx, 10), 0)
+    with pytest.raises(NotImplementedError):
+        gnnops.scatter_mul(src, idx, 0, dim_size=10)
+    rowptr = torch.tensor([0, 50], dtype=torch.int32).cuda()
+    with pytest.raises(NotImplementedError):
+        gnnops.spmm_csr(rowptr, idx, None, src)
+    with torch.no_grad():
+        assert ops.scatter(src, idx, 0, dim_size=10).shape == (10, 8)
+    assert gnnops.scatter(src, idx, 0, dim_size=10).grad_fn is not None
+    assert gnnops.segment_csr(src, torch.tensor([0, 20, 50]).cuda()).grad_fn is not None

@@ -76,6 +76,37 @@ def test_sort_special_values(gnnops, oracle):
     assert torch.isnan(v[-1]) and np.array_equal(v[:-1].cpu().numpy(), ev[:-1])
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16, torch.float64])
+@pytest.mark.parametrize("descending", [False, True])
+def test_sort_values_keep_the_input_bits(gnnops, dt, descending):
+    """values == input.gather(dim, indices) BIT FOR BIT, like torch.sort: -0.0 stays -0.0 (1 / value must not flip sign),
+    NaNs keep sign and payload. Checked on the bit patterns, in every sort form (1-D passes, on-chip rows, rows in two
+    halves + merge, segmented 64-bit keys, transposed dims)."""
+    g = torch.Generator().manual_seed(31)
+    bits = {torch.float32: torch.int32, torch.float16: torch.int16, torch.bfloat16: torch.int16, torch.float64: torch.int64}[dt]
+    shapes = [(50_000,)] if dt == torch.float64 else [(50_000,), (40, 3000), (3, 30000), (6, 50, 40), (2, 45000)]
+    for shape in shapes:
+        x = (torch.randn(shape, generator=g) * 2).to(dt)
+        r = torch.rand(shape, generator=g)
+        x = torch.where(r < 0.2, torch.zeros((), dtype=dt), x)
+        x = torch.where((r >= 0.2) & (r < 0.4), -torch.zeros((), dtype=dt), x)          # -0.0
+        x = torch.where((r >= 0.4) & (r < 0.45), torch.full((), float("nan"), dtype=dt), x)
+        xb = x.view(bits)
+        nan_pos = torch.isnan(x)
+        # NaNs with signs and payloads (low mantissa bits set; the sign bit on every other one)
+        payload = torch.randint(1, 64, shape, generator=g).to(bits)
+        sign = torch.where(torch.rand(shape, generator=g) < 0.5, torch.tensor(torch.iinfo(bits).min, dtype=bits), torch.zeros((), dtype=bits))
+        x = torch.where(nan_pos, (xb | payload | sign).view(dt), x)
+        for dim in range(len(shape)):
+            v, i = gnnops.sort(x.cuda(), dim=dim, descending=descending, stable=True)
+            ev, ei = torch.sort(x, dim=dim, descending=descending, stable=True)
+            assert torch.equal(i.cpu(), ei), (dt, shape, dim)
+            # gathered on the BIT view: torch's CPU gather / sort of 16-bit floats go through float and canonicalise NaNs
+            assert torch.equal(v.cpu().view(bits), x.view(bits).gather(dim, ei)), (dt, shape, dim)
+            if dt in (torch.float32, torch.float64):
+                assert torch.equal(v.cpu().view(bits), ev.view(bits)), (dt, shape, dim)
+
+
 @pytest.mark.parametrize("dname", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("m,n,D,nnz", [(1000, 800, 64, 20000), (300, 300, 256, 6000), (50, 70, 7, 900), (2000, 2000, 1, 30000),
                                        (64, 64, 320, 500), (40, 50, 257, 700), (30, 40, 1030, 500), (9, 9, 2049, 30)])
