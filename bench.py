@@ -4,11 +4,13 @@
 
 One "step" = one cold call of the hot path on one batch of synthetic input:
     torch_scatter.scatter_add(src, index, dim=0, dim_size=N)    (reference: op_bm_scripts/benchmark_scatter_add.py:15-19)
-with a 1-D row index — plan build (radix sort of the index) + segment reduce, nothing cached.
+with a 1-D row index — index partition + bucketed segment reduce, nothing cached.
 Workload at N=1 is BASELINE config 2 (configs[1]): N=10M destinations, E=50M source rows, D=128 fp32.
-With --gpus G every rank holds its own E=50M rows with destinations over G*10M rows, reduces locally
-into a partial [G*10M, D] buffer and ONE RCCL reduce-scatter hands each rank the slab it owns (weak
-scaling).
+With --gpus G the workload is BASELINE config 5's per-GPU share (configs[4]: N=80M, E=800M at 8 GPUs): every rank holds
+E=100M rows with GLOBAL destination ids over G*10M rows and owns a slab of 10M of them (weak scaling, SURVEY.md §8e);
+the step is gnnops.dist.sharded_scatter — ONE sparse reduce-scatter (all-to-all-v of the edges whose destination another
+rank owns) overlapped with the reduction of the own slab, one host read-back per step. `python bench.py --gpus G` without
+a launcher starts its G ranks itself (torch.distributed.run children, started before this process touches a GPU).
 
 `value` = algorithmic bytes (E*D*s + E*8 + N*D*s per step, x ranks) / wall time, inputs
 already resident in HBM. The JSON line also carries `roofline` (dominant kernel = the segment-reduce
@@ -55,7 +57,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 (BASELINE configs[1]) on one GPU, c5 (configs[4]'s per-GPU share) on several")
     ap.add_argument("--cut", type=float, default=None,
                     help="N>1 only: fraction of each rank's edges whose destination another rank owns (edge cut of the "
                          "partition; the rest fall uniformly in the rank's own rows). Default: 1/70 per peer, i.e. "
@@ -64,6 +67,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-ops", action="store_true", help="skip the per-op table (scatter_min/max/mean, index_select, index_add_)")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "c2" if args.gpus == 1 else "c5"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves, as fresh child processes, BEFORE anything here touches a GPU
+        # (torch is not even imported yet), relay their output (rank 0 prints the JSON line) and exit with their code
+        import socket
+        import subprocess
+
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
 
@@ -71,7 +89,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     # GNNOPS_BENCH_GLOO_ONE_GPU=1: rehearsal of the N>1 code path on a one-GPU box — every rank on cuda:0, gloo carrying
     # the device tensors (RCCL refuses two ranks on one device). Its timings mean nothing; its JSON line says so.
     rehearsal = os.environ.get("GNNOPS_BENCH_GLOO_ONE_GPU") == "1"
@@ -161,10 +179,15 @@ def main():
         "data": "synthetic (uniform random src, uniform random unsorted int64 row index, device RNG seed 42)" + (
             "" if world == 1 else f"; partitioned graph: {args.cut:.3f} of every rank's edges cross to rows of other ranks"),
         "config": {
-            "workload": f"{args.workload}: torch_scatter.scatter_add(src[E,D], index[E], dim=0, dim_size=N), "
+            "workload": f"{args.workload} ({'BASELINE configs[1]' if args.workload == 'c2' else 'BASELINE configs[4] per-GPU share' if args.workload == 'c5' else 'side workload'}): "
+                        f"torch_scatter.scatter_add(src[E,D], index[E], dim=0, dim_size=N), "
                         f"N={Ntot} E={E * world} D={D} fp32, layout R" + ("" if world == 1 else
-                        f"; per GPU E={E}, owned rows={Nloc}, edge cut {args.cut:.3f}, one sparse reduce-scatter "
-                        f"(all-to-all-v of per-destination partial rows over RCCL)"),
+                        f"; per GPU E={E}, owned rows={Nloc}; destination-partitioned graph with edge cut {args.cut:.3f} "
+                        f"(this fraction of every rank's edges points at rows another rank owns), ONE sparse reduce-scatter "
+                        f"(all-to-all-v over RCCL of those edges' (id, row) pairs) overlapped with the own-slab reduce; "
+                        f"beside it: other_cuts.cut_0 = config 5 read literally (edges pre-bucketed by owner, nothing to "
+                        f"exchange), other_cuts.uniform_random_graph.dense_reduce_scatter = north_star's single RCCL "
+                        f"reduce_scatter_tensor of partial [N,D] buffers"),
             "algorithmic_GB_per_step": round(job_bytes / 1e9, 3),
             "pct_of_hbm_peak": round(100 * value / (HBM_PEAK_GBS * world), 2),
         },
@@ -202,7 +225,8 @@ def main():
         #   cut (G-1)/G     an UNPARTITIONED uniform random graph: nearly every edge crosses; sparse and dense exchange
         try:
             result["other_cuts"] = {
-                "cut_0": dict(timed_variant(make_index(0.0), "sparse", few), note="destination-partitioned edges: empty exchange"),
+                "cut_0": dict(timed_variant(make_index(0.0), "sparse", few),
+                              note="BASELINE config 5 read literally: edges pre-bucketed by destination owner, empty exchange"),
             }
             if world > 1:
                 uni = make_index((world - 1) / world)
@@ -210,8 +234,8 @@ def main():
                     "cut": round((world - 1) / world, 4),
                     "sparse_exchange": timed_variant(uni, "sparse", few),
                     "dense_reduce_scatter": timed_variant(uni, "dense", few),
-                    "note": "xGMI-bound: bytes on the wire per rank ~ distinct remote destinations x 520 B (sparse) or "
-                            "(G-1)/G x N x 512 B (dense)",
+                    "note": "an UNPARTITIONED graph; xGMI-bound: bytes on the wire per rank ~ remote edges x 520 B (sparse) or "
+                            "(G-1)/G x N x 512 B (dense = north_star's single RCCL reduce_scatter_tensor of partial [N,D] buffers)",
                 }
                 del uni
         except Exception as exc:  # noqa: BLE001 - see above
@@ -335,6 +359,25 @@ def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters, pmc_applies):
             traffic = json.load(open(tpath)).get("bucket_reduce_kernel_f32_sum", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # What this box's memory system gives plain streams with the kernel's read : write ratio (5 rows + index in, 1 row
+    # out): sequential nontemporal streams, no index, no row structure (gnnops_diag_stream_mix) — and reads alone.
+    mix = None
+    try:
+        pieces = N * D * 4 // 16                       # one output row's worth of 16-B pieces per destination
+        reads = max(1, min(5, E // max(N, 1)))
+        if pieces * reads * 16 <= src.numel() * 4 and reads in (1, 2, 3, 4, 5):
+            def run_mix(dst):
+                _lib.check(lib.gnnops_diag_stream_mix(src.data_ptr(), dst, pieces, reads, _stream()), "diag_stream_mix")
+
+            mix_ms = _event_ms(torch, lambda: run_mix(out.data_ptr()), 5)
+            rd_ms = _event_ms(torch, lambda: run_mix(None), 5)
+            mix_bytes = pieces * 16 * (reads + 1)
+            mix = {"what": f"{reads} sequential nontemporal read streams : 1 write stream, same bytes per output row as the "
+                           f"kernel minus the index (gnnops_diag_stream_mix), measured in this run",
+                   "GBps": round(mix_bytes / mix_ms / 1e6, 1), "reads_only_GBps": round(pieces * 16 * reads / rd_ms / 1e6, 1),
+                   "kernel_frac_of_mix": round(achieved / (mix_bytes / mix_ms / 1e6), 4)}
+    except Exception as exc:  # reporting extra only
+        mix = {"error": str(exc)[:200]}
     return {
         "kernel": "bucket_reduce_kernel<float,SUM> (gnnops_bucket_reduce)",
         "bound": "hbm",
@@ -343,6 +386,9 @@ def roofline_leg(torch, gnnops, lib, src, index, N, E, D, iters, pmc_applies):
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
+        "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE at config 2; "
+                          "not a measurement of this run)" if traffic is not None else None,
+        "stream_mix_ceiling": mix,
         "kernel_ms": round(ms, 4),
         "algorithmic_bytes_per_launch": alg,
         "partition_ms": round(partition_ms, 4),
@@ -486,7 +532,7 @@ def cpu_baseline_leg(D):
     alg = algorithmic_bytes("scatter_add", Ns, Es, D)
     res = {
         "value": round(alg * reps / dt / 1e9, 3),
-        "unit": "GB/s",
+        "unit": "GB/s (algorithmic bytes / wall time, on a 1/10 sample of config 2: N=1M E=5M)",
         "cores": 1,
         "kind": "port",
         "sample": f"oracle/gnnops_oracle.c ora_scatter_add_rows_f32, N={Ns} E={Es} D={D} fp32 (1/10 of config 2), "

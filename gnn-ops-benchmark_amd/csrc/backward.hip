@@ -93,3 +93,47 @@ extern "C" int gnnops_sddmm(const int64_t* rows_a, const int64_t* rows_b, const 
     gnnops_set_error("sddmm: unknown dtype %d", dtype);
     return GNNOPS_EINVAL;
 }
+
+// ---- destination-partitioned scatter across GPUs (gnnops/dist.py): how many of this rank's edges go to each owner ----
+// counts[g] = #{e : g * per <= index[e] < (g + 1) * per}, g < G <= 64 (contiguous slabs of `per` destination rows).
+// One streaming read of the index; per wave one ballot per owner, one LDS add per wave and owner, one global add per
+// workgroup and owner.
+namespace {
+__global__ __launch_bounds__(256) void owner_counts_kernel(const int64_t* __restrict__ index, int64_t E, int64_t per, int G,
+                                                           unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int s_cnt[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (E + stride - 1) / stride;   // every wave runs the same number of rounds: ballots stay full
+    for (int64_t r = 0; r < rounds; ++r) {
+        const int64_t e = r * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        int owner = -1;
+        if (e < E) {
+            const int64_t d = index[e];
+            owner = 0;
+            for (int g = 1; g < G; ++g) owner += (d >= (int64_t)g * per) ? 1 : 0;
+        }
+        for (int g = 0; g < G; ++g) {
+            const unsigned long long m = __ballot(owner == g);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cnt[g], (unsigned int)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+}  // namespace
+
+extern "C" int gnnops_owner_counts(const int64_t* index, int64_t E, int64_t rows_per_owner, int owners, int64_t* counts,
+                                   gnnops_stream_t s) {
+    hipStream_t stream = (hipStream_t)s;
+    GNNOPS_REQUIRE(E >= 0 && rows_per_owner > 0 && owners >= 1 && owners <= 64, GNNOPS_EINVAL,
+                   "owner_counts: bad argument (E=%lld per=%lld owners=%d)", (long long)E, (long long)rows_per_owner, owners);
+    GNNOPS_REQUIRE(counts && (E == 0 || index), GNNOPS_EINVAL, "owner_counts: null pointer");
+    if (hipMemsetAsync(counts, 0, sizeof(int64_t) * owners, stream) != hipSuccess) return gnnops_check_launch("owner_counts memset");
+    if (E == 0) return GNNOPS_OK;
+    const int grid = gnnops_grid_cap(gnnops_cdiv(E, 256 * 8), 256 * 8);
+    hipLaunchKernelGGL(owner_counts_kernel, dim3(grid), dim3(256), 0, stream, index, E, rows_per_owner, owners,
+                       (unsigned long long*)counts);
+    return gnnops_check_launch("owner_counts");
+}

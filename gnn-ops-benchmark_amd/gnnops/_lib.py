@@ -19,6 +19,7 @@ _i64, _vp, _ci, _sz = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_si
 SIGNATURES = {
     "gnnops_version": (_ci, []),
     "gnnops_last_error": (ctypes.c_char_p, []),
+    "gnnops_diag_stream_mix": (_ci, [_vp, _vp, _i64, _ci, _vp]),
     "gnnops_index_max": (_ci, [_vp, _i64, _vp, _vp]),
     "gnnops_plan_workspace_bytes": (_sz, [_i64, _i64]),
     "gnnops_plan_build": (_ci, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     "gnnops_spspmm_expand": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp]),
     "gnnops_rowptr_workspace_bytes": (_sz, [_i64]),
     "gnnops_rowptr_from_sorted": (_ci, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "gnnops_owner_counts": (_ci, [_vp, _i64, _i64, _ci, _vp, _vp]),
     "gnnops_rowptr_expand": (_ci, [_vp, _i64, _i64, _vp, _vp]),
     "gnnops_sddmm": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _ci, _vp]),
     "gnnops_segment_composite": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp]),

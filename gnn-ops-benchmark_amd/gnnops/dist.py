@@ -2,25 +2,38 @@
 
 One process per GPU. Edges are partitioned by position (rank g holds src_g [E_g, D] and index_g [E_g]
 with GLOBAL destination ids anywhere in [0, n_total)); destination rows are partitioned contiguously
-(rank g owns rows [g*n_total/G, (g+1)*n_total/G)). The path has exactly one exchange step, and two forms of it:
+(rank g owns rows [g*n_total/G, (g+1)*n_total/G)). The path has exactly one exchange step, in three forms:
 
-``exchange="sparse"`` (default) — a reduce-scatter of only what is there:
-  1. one windowed partition of this rank's edges: those whose destination it owns are bucketed under their local id
+``exchange="sparse"`` (default) — a reduce-scatter of only what is there. For sums (the headline path):
+  1. `gnnops_owner_counts`: how many of this rank's edges go to each owner — one read of the index; the counts of all
+     ranks are swapped (a [G]-element all-to-all) and read back: the ONE host synchronisation of the step, issued on a
+     side stream so that step 2 is already running underneath it;
+  2. one windowed partition of this rank's edges: those whose destination it owns are bucketed under their local id
      (stage 1 of the single-GPU one-shot scatter), all others come out set aside in source order;
-  2. only the set-aside edges are sorted by destination and reduced per DISTINCT destination into compact
-     (id, row) lists, grouped by owner (ids ascend, so the groups are contiguous slices);
-  3. ONE all-to-all-v of those lists (RCCL over xGMI; `torch.distributed` backend "nccl" is RCCL on ROCm) —
-     issued asynchronously, while
-  4. the edges this rank owns itself are reduced straight into its slab;
-  5. the received rows are scatter-reduced into the slab.
-  (fp32 sums; other dtypes / reduces build one full plan over the global ids instead of 1-2, same exchange.)
-  Bytes on the wire per rank = (#distinct remote destinations touched) x (row + 8), i.e. proportional to the
-  edge cut of the partition, not to n_total. RCCL has no sparse reduce-scatter; this composes one from
-  all_to_all_single and the local segment reduce.
+  3. the set-aside positions are ordered by owner (one stable sort of their 3-bit owner ids) and their (destination id,
+     source row) pairs gathered into the send lists — an EDGE list: nothing is summed before the wire, so every size is
+     known from step 1 and no second read-back is needed (on a partitioned graph a rank rarely holds two edges to the
+     same remote destination: compacting per destination would save ~7 % of the bytes at the price of a sort by
+     destination, a unique and a second synchronisation — that is ``exchange="compact"``);
+  4. the all-to-all-v of ids and rows (RCCL over xGMI; `torch.distributed` backend "nccl" is RCCL on ROCm), issued
+     asynchronously, while
+  5. the edges this rank owns itself are reduced straight into its slab (bucket.hip);
+  6. the received rows are scatter-added into the slab (rows nothing touches are skipped, not rewritten).
+  Bytes on the wire per rank = (#edges whose destination another rank owns) x (row + 8), i.e. proportional to the edge
+  cut of the partition, not to n_total. RCCL has no sparse reduce-scatter; this composes one.
+
+``exchange="compact"`` — the same exchange of per-DESTINATION partial rows: every rank first reduces its edges per distinct
+  destination (plan + segment reduce) and sends compact (id, row) lists; what min / max / mul and `return_arg` use (a
+  received row must be a finished partial result there), and what pays on graphs where a rank holds many edges to the same
+  remote destination. Two host read-backs (the number of distinct destinations, then the counts).
 
 ``exchange="dense"`` — local scatter into a partial [n_total, D] buffer, then ONE `reduce_scatter_tensor`.
   Bytes on the wire per rank = (G-1)/G x n_total x row whatever the cut; kept for comparison and for
   graphs so dense that every rank touches every destination.
+
+min / max with ``return_arg=True`` return the GLOBAL position of the extremum (rank-major: position e of rank g is
+sum(E_h, h < g) + e; ties go to the smallest global position, empty groups get sum(E_h)): the (value, index) pair
+reduction of SURVEY.md §8(f) — the positions travel beside the compact rows and the owner picks per destination.
 
 The reference has no distributed code; this module is the MI355X design for config 5.
 The local pieces are injectable (`local=` / `local_scatter=`) so the exchange logic is testable on CPU with the
@@ -43,36 +56,156 @@ def owned_rows(n_total, rank, world):
 
 
 class HipLocal:
-    """The local (per-GPU) pieces of the sparse exchange, on our kernels: plan build + segment reduce."""
+    """The local (per-GPU) pieces of the sparse exchange, on our kernels."""
 
-    def split(self, src, index, n_total, lo, hi, reduce, own_dense):
+    # ---- edge-list form (sums) ----------------------------------------------------------------------------------
+    def owner_counts(self, index, per, world):
+        """Device int64 [world]: how many of this rank's positions go to each owner's slab of `per` rows."""
+        from . import _lib
+        from .ops import _require_gpu, _stream, check
+
+        _require_gpu(index)
+        index = index.contiguous()
+        counts = torch.empty(world, dtype=torch.int64, device=index.device)
+        with torch.cuda.device(index.device):
+            check(_lib.load().gnnops_owner_counts(index.data_ptr(), index.numel(), per, world, counts.data_ptr(), _stream()),
+                  "owner_counts")
+        return counts
+
+    def route_ready(self, src, lo, hi):
+        """Can `route` take this operand? (fp32 rows of whole 16-B lanes, a slab of more than one bucket.) The answer may
+        differ between ranks: both forms speak the same exchange protocol."""
+        return (src.is_cuda and src.dim() == 2 and src.dtype == torch.float32 and hi - lo > 256 and src.size(1) % 4 == 0
+                and src.size(0) < 2 ** 31 and src.data_ptr() % 16 == 0)
+
+    def route_begin(self, src, index, lo, hi):
+        """Stage 1 of `route`: the windowed partition, enqueued BEFORE the host reads the owner counts back, so that the
+        device is busy underneath that round trip. Returns the state `route` continues from."""
+        from . import _lib
+        from .ops import _stream, check
+
+        src, index = src.contiguous(), index.contiguous()
+        E, n_loc = src.size(0), hi - lo
+        if E == 0:
+            return (src, index, None)
+        L = _lib.load()
+        ws_bytes = L.gnnops_bucket_workspace_bytes(E, n_loc)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
+        with torch.cuda.device(src.device):
+            check(L.gnnops_bucket_partition_window(index.data_ptr(), E, lo, n_loc, ws.data_ptr(), ws_bytes, _stream()),
+                  "bucket_partition_window")
+        return (src, index, ws)
+
+    def route(self, state, n_total, lo, hi, send_splits, rank):
+        """Continue from `route_begin` with the owner counts known on the host: returns ``(own, send_ids, send_rows)`` —
+        the (global destination id, source row) pairs of every position another rank owns, grouped by owner in source
+        order (``send_splits[g]`` of them for owner g, none for ``rank``), and the callable that reduces the own part into
+        a dense slab (written into ``out`` when one is passed)."""
+        import ctypes
+
+        from . import _lib
+        from .ops import _stream, check, index_select
+        from .sparse import sort
+
+        src, index, ws = state
+        E, D = src.shape
+        n_loc, dev = hi - lo, src.device
+        per = n_loc
+        L = _lib.load()
+        n_own = send_splits[rank]
+        R = E - n_own
+        if sum(send_splits) != E:
+            raise RuntimeError("sharded_scatter: owner counts do not add up to the number of edges (index out of range?)")
+        if R:
+            ko, vo, bo = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+            check(L.gnnops_bucket_layout(E, n_loc, ctypes.byref(ko), ctypes.byref(vo), ctypes.byref(bo)), "bucket_layout")
+            # positions set aside by the windowed partition, ascending: everything behind the n_own own ones
+            rpos = ws[vo.value + 4 * n_own: vo.value + 4 * E].view(torch.int32).long()
+            ids = index_select(index, 0, rpos)
+            owner = torch.div(ids, per, rounding_mode="floor").to(torch.int32)
+            _, order = sort(owner, stable=True)                  # stable: source order inside an owner
+            send_ids = index_select(ids, 0, order)
+            send_rows = index_select(src, 0, index_select(rpos, 0, order))
+        else:
+            send_ids = torch.empty(0, dtype=torch.int64, device=dev)
+            send_rows = torch.empty((0, D), dtype=src.dtype, device=dev)
+
+        def own(out=None):
+            slab = out if out is not None else torch.empty((n_loc, D), dtype=src.dtype, device=dev)
+            if ws is None:
+                return slab.zero_()
+            hub_bytes = L.gnnops_hub_workspace_bytes(E, D, _lib.SUM)   # heavy destinations: csrc/hub.h
+            hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=dev) if hub_bytes else None
+            with torch.cuda.device(dev):
+                check(L.gnnops_bucket_reduce_hubs(src.data_ptr(), ws.data_ptr(), slab.data_ptr(), None, E, D, n_loc, _lib.F32,
+                                                  _lib.SUM, 0, hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes,
+                                                  _stream()), "bucket_reduce")
+            return slab
+
+        return own, send_ids, send_rows
+
+    # ---- compact form (any reduce; what min / max / mul and return_arg use) -----------------------------------
+
+    def split(self, src, index, n_total, lo, hi, reduce, own_dense, want_arg=False):
         """Reduce this rank's edges per destination and split the result by ownership.
 
-        Returns ``(own, ids, rows)``: ``ids`` int64 ascending = the distinct destinations outside [lo, hi) this rank
-        touches, ``rows`` [len(ids), D] their reduced rows. ``own`` is a callable that, when invoked, produces the own
-        part — the dense slab [hi-lo, D] if ``own_dense`` (sum: untouched rows are 0, the neutral element; written into
-        ``out`` when one is passed), else the compact pair (ids_own - lo, rows_own) — so the caller can start the
-        exchange first and overlap the two.
+        Returns ``(own, ids, rows, args)``: ``ids`` int64 ascending = the distinct destinations outside [lo, hi) this
+        rank touches, ``rows`` [len(ids), D] their reduced rows, ``args`` (``want_arg``, min / max) int64 [len(ids), D] the
+        LOCAL position of each extremum, else None. ``own`` is a callable that, when invoked, produces the own part — the
+        dense slab [hi-lo, D] if ``own_dense`` (sum: untouched rows are 0, the neutral element; written into ``out`` when
+        one is passed), else the compact triple (ids_own - lo, rows_own, args_own) — so the caller can start the exchange
+        first and overlap the two. One plan over the global ids; its row pointer restricted to touched rows is itself a
+        CSR row pointer over perm (untouched rows are empty), so compact reductions are plain segment reductions.
         """
-        from .ops import _require_gpu
+        from .ops import Plan, _require_gpu
 
         _require_gpu(src, index)
         if src.dim() != 2 or index.dim() != 1 or index.numel() != src.size(0):
             raise ValueError("sharded_scatter: src must be [E, D] with a 1-D index of E destinations")
         if src.size(0) >= 2 ** 31 or n_total >= 2 ** 31:
-            raise NotImplementedError("sharded_scatter(exchange='sparse'): E and n_total must be < 2^31")
+            raise NotImplementedError("sharded_scatter(exchange='compact'): E and n_total must be < 2^31")
         src = src.contiguous()
         index = index.contiguous()
-        D = src.size(1)
-        windowed = (own_dense and src.dtype == torch.float32 and hi - lo > 256 and src.size(0) > 0
-                    and D % 4 == 0 and src.data_ptr() % 16 == 0)
-        if windowed:
-            return self._split_windowed(src, index, n_total, lo, hi, reduce)
-        return self._split_planned(src, index, n_total, lo, hi, reduce, own_dense)
+        E, D = src.shape
+        dev = src.device
+        plan = Plan(index, n_total)
+        rowptr, perm = plan.rowptr, plan.perm
+
+        def seg(rp, n_rows, out, arg=None):
+            self._seg(src, rp, perm, n_rows, out, reduce, arg)
+
+        touched = rowptr[1:] != rowptr[:-1]
+        own_touched = None if own_dense else touched[lo:hi].nonzero().squeeze(1)
+        touched[lo:hi] = False
+        ids = touched.nonzero().squeeze(1)                       # int64, ascending, remote only (sizes: a read-back)
+        # ids below the own range (owners 0 .. rank-1) and above it: two runs of the compact row pointer
+        below = ids < lo
+        ids_lo, ids_hi = ids[below], ids[~below]
+        n_lo, n_hi = ids_lo.numel(), ids_hi.numel()
+        # compact rowptrs: untouched rows are empty, so consecutive touched rows are adjacent in perm
+        crow = torch.cat([rowptr[ids_lo], rowptr[lo:lo + 1], rowptr[ids_hi], rowptr[n_total:n_total + 1]])
+        rows = torch.empty((ids.numel(), D), dtype=src.dtype, device=dev)
+        args = torch.empty((ids.numel(), D), dtype=torch.int64, device=dev) if want_arg else None
+        seg(crow[: n_lo + 1], n_lo, rows[:n_lo], None if args is None else args[:n_lo])
+        seg(crow[n_lo + 1:], n_hi, rows[n_lo:], None if args is None else args[n_lo:])
+
+        def own(out=None):
+            if own_dense:
+                slab = out if out is not None else torch.empty((hi - lo, D), dtype=src.dtype, device=dev)
+                seg(rowptr[lo:hi + 1], hi - lo, slab)
+                return slab
+            orow = torch.cat([rowptr[lo:hi][own_touched], rowptr[hi:hi + 1]])
+            orows = torch.empty((own_touched.numel(), D), dtype=src.dtype, device=dev)
+            oargs = torch.empty((own_touched.numel(), D), dtype=torch.int64, device=dev) if want_arg else None
+            seg(orow, own_touched.numel(), orows, oargs)
+            return own_touched, orows, oargs
+
+        return own, ids, rows, args
 
     @staticmethod
-    def _seg(src, crow, perm, n_rows, out, reduce):
-        """out[i] = reduce over src[perm[crow[i] : crow[i+1]]] (crow int32: absolute positions into perm)."""
+    def _seg(src, crow, perm, n_rows, out, reduce, arg=None):
+        """out[i] = reduce over src[perm[crow[i] : crow[i+1]]] (crow int32: absolute positions into perm); ``arg`` (min /
+        max) receives the position in src of each extremum."""
         from . import _lib
         from .ops import REDUCE_CODE, _dtype_code, _stream, check
 
@@ -84,99 +217,11 @@ class HipLocal:
         hub_bytes = L.gnnops_hub_workspace_bytes(E, D, rcode)   # heavy destinations: csrc/hub.h
         hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=src.device) if hub_bytes else None
         with torch.cuda.device(src.device):
-            check(L.gnnops_segment_reduce_hubs(src.data_ptr(), crow.data_ptr(), perm.data_ptr(), out.data_ptr(), None, 1,
+            check(L.gnnops_segment_reduce_hubs(src.data_ptr(), crow.data_ptr(), perm.data_ptr(), out.data_ptr(),
+                                               arg.data_ptr() if arg is not None else None, 1,
                                                E, D, n_rows, _dtype_code(src, "sharded_scatter"), rcode, 0,
                                                hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream()),
                   "segment_reduce")
-
-    def _split_windowed(self, src, index, n_total, lo, hi, reduce):
-        """fp32 sums: ONE windowed partition serves both sides. Positions whose destination lies in [lo, hi) are bucketed
-        under their local id and reduced straight into the slab (bucket.hip, the one-shot form of the single-GPU op);
-        all other positions come out of the partition set aside in order, and only those (a `cut` fraction of E) are
-        sorted by destination and reduced per distinct destination."""
-        import ctypes
-
-        from . import _lib
-        from .ops import _stream, check
-        from .sparse import sort
-
-        L = _lib.load()
-        E, D = src.shape
-        n_loc = hi - lo
-        dev = src.device
-        ws_bytes = L.gnnops_bucket_workspace_bytes(E, n_loc)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            check(L.gnnops_bucket_partition_window(index.data_ptr(), E, lo, n_loc, ws.data_ptr(), ws_bytes, _stream()),
-                  "bucket_partition_window")
-        ko, vo, bo = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
-        check(L.gnnops_bucket_layout(E, n_loc, ctypes.byref(ko), ctypes.byref(vo), ctypes.byref(bo)), "bucket_layout")
-        nb = (n_loc + 255) // 256
-        bptr = ws[bo.value: bo.value + 4 * (nb + 1)].view(torch.int32)
-        first_remote = int(bptr[nb].item())                       # positions set aside start here
-        remote_pos = ws[vo.value + 4 * first_remote: vo.value + 4 * E].view(torch.int32)   # ascending (stable)
-        if remote_pos.numel():
-            rpos64 = remote_pos.long()
-            sorted_ids, order = sort(index[rpos64].to(torch.int32))          # stable: source order inside a destination
-            ids32, counts = torch.unique_consecutive(sorted_ids, return_counts=True)
-            crow = torch.zeros(ids32.numel() + 1, dtype=torch.int32, device=dev)
-            crow[1:] = torch.cumsum(counts, 0)
-            perm = rpos64[order].to(torch.int32)
-            ids = ids32.long()
-            rows = torch.empty((ids.numel(), D), dtype=src.dtype, device=dev)
-            self._seg(src, crow, perm, ids.numel(), rows, reduce)
-        else:
-            ids = torch.empty(0, dtype=torch.int64, device=dev)
-            rows = torch.empty((0, D), dtype=src.dtype, device=dev)
-
-        def own(out=None):
-            slab = out if out is not None else torch.empty((n_loc, D), dtype=src.dtype, device=dev)
-            hub_bytes = L.gnnops_hub_workspace_bytes(E, D, _lib.SUM)   # heavy destinations: csrc/hub.h
-            hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=dev) if hub_bytes else None
-            with torch.cuda.device(dev):
-                check(L.gnnops_bucket_reduce_hubs(src.data_ptr(), ws.data_ptr(), slab.data_ptr(), None, E, D, n_loc, _lib.F32,
-                                                  _lib.SUM, 0, hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes,
-                                                  _stream()), "bucket_reduce")
-            return slab
-
-        return own, ids, rows
-
-    def _split_planned(self, src, index, n_total, lo, hi, reduce, own_dense):
-        """Any dtype / reduce: one full plan over the global ids; its row pointer restricted to touched rows is itself a
-        CSR row pointer over perm (untouched rows are empty), so compact reductions are plain segment reductions."""
-        from .ops import Plan
-
-        E, D = src.shape
-        dev = src.device
-        plan = Plan(index, n_total)
-        rowptr, perm = plan.rowptr, plan.perm
-
-        def seg(rp, n_rows, out):
-            self._seg(src, rp, perm, n_rows, out, reduce)
-
-        touched = rowptr[1:] != rowptr[:-1]
-        own_touched = None if own_dense else touched[lo:hi].nonzero().squeeze(1)
-        touched[lo:hi] = False
-        ids = touched.nonzero().squeeze(1)                       # int64, ascending, remote only
-        n_lo = int(torch.searchsorted(ids, lo).item())           # ids below the own range (owners 0 .. rank-1)
-        n_hi = ids.numel() - n_lo
-        # compact rowptrs: untouched rows are empty, so consecutive touched rows are adjacent in perm
-        crow = torch.cat([rowptr[ids[:n_lo]], rowptr[lo:lo + 1], rowptr[ids[n_lo:]], rowptr[n_total:n_total + 1]])
-        rows = torch.empty((ids.numel(), D), dtype=src.dtype, device=dev)
-        seg(crow[: n_lo + 1], n_lo, rows[:n_lo])
-        seg(crow[n_lo + 1:], n_hi, rows[n_lo:])
-
-        def own(out=None):
-            if own_dense:
-                slab = out if out is not None else torch.empty((hi - lo, D), dtype=src.dtype, device=dev)
-                seg(rowptr[lo:hi + 1], hi - lo, slab)
-                return slab
-            orow = torch.cat([rowptr[lo:hi][own_touched], rowptr[hi:hi + 1]])
-            orows = torch.empty((own_touched.numel(), D), dtype=src.dtype, device=dev)
-            seg(orow, own_touched.numel(), orows)
-            return own_touched, orows
-
-        return own, ids, rows
 
     def spmm_split(self, row, col, value, mat, n_total, lo, hi):
         """Source-partitioned SpMM: this rank's nonzeros (global output row, LOCAL column into its slab `mat` [K_g, D],
@@ -212,9 +257,11 @@ class HipLocal:
 
         touched = rowptr[1:] != rowptr[:-1]
         touched[lo:hi] = False
-        ids = touched.nonzero().squeeze(1)
-        n_lo = int(torch.searchsorted(ids, lo).item())
-        crow = torch.cat([rowptr[ids[:n_lo]], rowptr[lo:lo + 1], rowptr[ids[n_lo:]], rowptr[n_total:n_total + 1]])
+        ids = touched.nonzero().squeeze(1)                       # sizes the compact lists: a read-back
+        below = ids < lo
+        ids_lo, ids_hi = ids[below], ids[~below]
+        n_lo = ids_lo.numel()
+        crow = torch.cat([rowptr[ids_lo], rowptr[lo:lo + 1], rowptr[ids_hi], rowptr[n_total:n_total + 1]])
         rows = torch.empty((ids.numel(), D), dtype=mat.dtype, device=dev)
         mm(crow[: n_lo + 1], n_lo, rows[:n_lo])
         mm(crow[n_lo + 1:], ids.numel() - n_lo, rows[n_lo:])
@@ -234,47 +281,65 @@ class HipLocal:
             scatter(rows, ids_local, 0, out=slab, reduce="sum")
         return slab
 
-    def combine(self, rows, ids_local, n_local, reduce):
-        """Dense slab [n_local, D] from compact contributions; destinations nobody touched read 0 (torch_scatter)."""
+    def combine(self, rows, ids_local, n_local, reduce, want_arg=False):
+        """Dense slab [n_local, D] from compact contributions; destinations nobody touched read 0 (torch_scatter). With
+        ``want_arg`` (min / max) also the position in `rows` of each extremum (len(rows) where nothing arrived)."""
         from .ops import scatter
 
         res = scatter(rows, ids_local, 0, dim_size=n_local, reduce=reduce)
+        if want_arg:
+            return res
         return res[0] if isinstance(res, tuple) else res
 
 
-def _exchange(ids, rows, per, rank, world, group):
-    """All-to-all-v of compact (id, row) lists: ids ascend, so owner o's share is one contiguous slice."""
-    dev = ids.device
-    bounds = torch.searchsorted(ids, torch.arange(world + 1, device=dev, dtype=ids.dtype) * per)
-    send_counts = (bounds[1:] - bounds[:-1]).to(torch.int64)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-    send_splits, recv_splits = send_counts.tolist(), recv_counts.tolist()
-    if send_splits[rank] != 0:
-        raise RuntimeError("sharded_scatter: own destinations must not enter the exchange")
+def _read_counts(send_counts, world, group):
+    """Swap the per-owner counts with every rank and read both vectors back in ONE device-to-host copy: returns
+    (send_splits, recv_splits) as lists. Runs on the CURRENT stream (callers put it on a side stream to keep the
+    device busy underneath)."""
+    both = torch.empty(2 * world, dtype=torch.int64, device=send_counts.device)
+    both[:world] = send_counts
+    dist.all_to_all_single(both[world:], both[:world], group=group)
+    host = both.tolist()
+    return host[:world], host[world:]
+
+
+def _swap(tensors, send_splits, recv_splits, group):
+    """All-to-all-v of row lists that are grouped by owner: returns (received tensors, work handles)."""
     n_recv = sum(recv_splits)
-    recv_ids = torch.empty(n_recv, dtype=ids.dtype, device=dev)
-    recv_rows = torch.empty((n_recv,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
-    works = [dist.all_to_all_single(recv_ids, ids, recv_splits, send_splits, group=group, async_op=True),
-             dist.all_to_all_single(recv_rows, rows, recv_splits, send_splits, group=group, async_op=True)]
-    return recv_ids, recv_rows, works
+    outs, works = [], []
+    for t in tensors:
+        out = torch.empty((n_recv,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        works.append(dist.all_to_all_single(out, t, recv_splits, send_splits, group=group, async_op=True))
+        outs.append(out)
+    return outs, works
+
+
+def _counts_by_owner(ids, per, world):
+    """Device int64 [world]: sizes of the owner slices of an ascending id list."""
+    bounds = torch.searchsorted(ids, torch.arange(world + 1, device=ids.device, dtype=ids.dtype) * per)
+    return (bounds[1:] - bounds[:-1]).to(torch.int64)
 
 
 def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, local_scatter=None, out_slab=None,
-                    exchange="sparse", local=None):
+                    exchange="sparse", local=None, return_arg=False):
     """Scatter-reduce this rank's edges into global destinations and return the slab this rank owns.
 
     sum / min / max / mul: one exchange (see the module docstring); mean = sums and counts, then divide.
-    (arg_out across ranks needs a (value, index) pair reduction — SURVEY.md §8f — and is not provided.)
+    ``return_arg`` (min / max): returns ``(slab, arg)`` with the GLOBAL (rank-major) position of each extremum.
     `local_scatter` given without `local` selects the dense form (it is all that form needs).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = owned_rows(n_total, rank, world)
+    per = hi - lo
     if local is None and local_scatter is not None:
         exchange = "dense"
-    if exchange not in ("sparse", "dense"):
+    if exchange not in ("sparse", "compact", "dense"):
         raise ValueError(f"sharded_scatter: unknown exchange {exchange!r}")
+    if return_arg and reduce not in ("min", "max"):
+        raise ValueError("sharded_scatter: return_arg needs reduce='min' or 'max'")
+    if return_arg and exchange == "dense":
+        raise NotImplementedError("sharded_scatter: return_arg needs the sparse / compact exchange")
     if reduce == "mean":
         kw = dict(group=group, local_scatter=local_scatter, exchange=exchange, local=local)
         sums = sharded_scatter(src_local, index_local, n_total, "sum", **kw)
@@ -286,27 +351,70 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
             return out_slab
         return res
 
-    if exchange == "sparse":
+    if exchange in ("sparse", "compact"):
         if reduce not in _SPARSE_REDUCES:
             raise ValueError(f"sharded_scatter: reduce {reduce!r} is not supported")
         if local is None:
             local = HipLocal()
-        own_dense = reduce in ("sum", "add")
-        own, ids, rows = local.split(src_local, index_local, n_total, lo, hi, reduce, own_dense)
-        recv_ids, recv_rows, works = _exchange(ids, rows, hi - lo, rank, world, group)
-        direct = own_dense and out_slab is not None and out_slab.is_contiguous() and out_slab.dtype == src_local.dtype
+        is_sum = reduce in ("sum", "add")
+        edge_list = (exchange == "sparse" and is_sum and hasattr(local, "route") and local.route_ready(src_local, lo, hi))
+        direct = is_sum and out_slab is not None and out_slab.is_contiguous() and out_slab.dtype == src_local.dtype
+        send_args = None
+        if edge_list:
+            # the owner counts go round on a side stream while the partition of step 2 is already queued behind them on the
+            # main one: the host waits for the counts only, the device never idles
+            counts = local.owner_counts(index_local, per, world)
+            ready = _mark(counts)                                  # right behind the counting kernel
+            state = local.route_begin(src_local, index_local, lo, hi)
+            send_splits, recv_splits = _side_stream_counts(counts, ready, world, group)
+            own, send_ids, send_rows = local.route(state, n_total, lo, hi, send_splits, rank)
+        else:
+            own, send_ids, send_rows, send_args = local.split(src_local, index_local, n_total, lo, hi, reduce, is_sum,
+                                                              want_arg=return_arg)
+            send_splits, recv_splits = _read_counts(_counts_by_owner(send_ids, per, world), world, group)
+        if send_splits[rank] != 0 and not edge_list:
+            raise RuntimeError("sharded_scatter: own destinations must not enter the exchange")
+        if edge_list:
+            send_splits = list(send_splits)
+            send_splits[rank] = 0          # the own edges stay here (recv_splits[rank] is the mirror of it)
+            recv_splits = list(recv_splits)
+            recv_splits[rank] = 0
+        payload = [send_ids, send_rows]
+        if return_arg:
+            e_sizes = torch.empty(world, dtype=torch.int64, device=src_local.device)
+            dist.all_gather_into_tensor(e_sizes, torch.tensor([src_local.shape[0]], dtype=torch.int64, device=src_local.device),
+                                        group=group)
+            e_sizes = e_sizes.tolist()
+            e_off, e_total = sum(e_sizes[:rank]), sum(e_sizes)
+            payload.append(send_args + e_off)          # positions travel as GLOBAL (rank-major) positions
+        (recv_ids, recv_rows, *recv_rest), works = _swap(payload, send_splits, recv_splits, group)
         own_part = own(out_slab) if direct else own()          # runs while the all-to-all is in flight
         for w in works:
             w.wait()
-        if own_dense:
+        if is_sum:
             slab = local.accumulate(own_part, recv_rows, recv_ids - lo, reduce)
         else:
-            own_ids, own_rows = own_part
-            slab = local.combine(torch.cat([own_rows, recv_rows]), torch.cat([own_ids, recv_ids - lo]), hi - lo, reduce)
+            own_ids, own_rows, own_args = own_part
+            # contributions in RANK order (received from ranks below, own, received from ranks above): the first
+            # minimiser among ties is then the one with the smallest global position
+            n_before = sum(recv_splits[:rank])
+            rows = torch.cat([recv_rows[:n_before], own_rows, recv_rows[n_before:]])
+            ids_local = torch.cat([recv_ids[:n_before] - lo, own_ids, recv_ids[n_before:] - lo])
+            if return_arg:
+                slab, apos = local.combine(rows, ids_local, per, reduce, want_arg=True)
+                args = torch.cat([recv_rest[0][:n_before], own_args + e_off, recv_rest[0][n_before:]])
+                n_rows = rows.size(0)
+                if n_rows:
+                    arg = torch.where(apos < n_rows, args.gather(0, apos.clamp(max=n_rows - 1)),
+                                      torch.full((), e_total, dtype=torch.int64, device=apos.device))
+                else:
+                    arg = torch.full_like(apos, e_total)
+            else:
+                slab = local.combine(rows, ids_local, per, reduce)
         if out_slab is not None and slab is not out_slab:
             out_slab.copy_(slab)
-            return out_slab
-        return slab
+            slab = out_slab
+        return (slab, arg) if return_arg else slab
 
     # ---- dense: partial [n_total, D] + one reduce-scatter
     if local_scatter is None:
@@ -330,13 +438,40 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
     return out_slab
 
 
+_side_stream = {}
+
+
+def _mark(t):
+    """An event on the current stream right behind the kernel that produced the device tensor `t` (None on CPU)."""
+    if not t.is_cuda:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+    return ev
+
+
+def _side_stream_counts(counts, ready, world, group):
+    """`_read_counts` on a side stream that waits for `ready` only: the host blocks until the counts are back, the main
+    stream keeps running what was queued behind them. CPU tensors (the gloo tests' stand-ins) have no streams: plain call."""
+    if ready is None:
+        return _read_counts(counts, world, group)
+    dev = counts.device
+    side = _side_stream.get(dev)
+    if side is None:
+        side = _side_stream[dev] = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        counts.record_stream(side)
+        return _read_counts(counts, world, group)
+
+
 def sharded_spmm(index_local, value_local, n_total, matrix_local, group=None, out_slab=None, local=None):
     """Source-partitioned SpMM across the GPUs of one node (SURVEY.md §8e "column(src)-partitioned A with B slabs").
 
     Rank g holds the slab ``matrix_local`` [K_g, D] of the dense operand (the features of the source nodes it owns) and
     the nonzeros whose column falls in that slab: ``index_local`` [2, nnz_g] = (GLOBAL output row, LOCAL column),
     ``value_local`` [nnz_g] or None. Returns the slab of ``A @ B`` this rank owns (rows [g*n_total/G, (g+1)*n_total/G)).
-    Same single exchange as sharded_scatter(exchange="sparse"): partial output rows for rows other ranks own travel as
+    Same single exchange as sharded_scatter(exchange="compact"): partial output rows for rows other ranks own travel as
     compact (id, row) lists in one all-to-all-v while the own slab is multiplied; the received rows are added in.
     (Destination-partitioned A with a replicated B needs no collective: that is a plain local ``gnnops.spmm``.)
     """
@@ -348,7 +483,10 @@ def sharded_spmm(index_local, value_local, n_total, matrix_local, group=None, ou
     if index_local.dim() != 2 or index_local.size(0) != 2:
         raise ValueError("sharded_spmm: index_local must be [2, nnz]")
     own, ids, rows = local.spmm_split(index_local[0], index_local[1], value_local, matrix_local, n_total, lo, hi)
-    recv_ids, recv_rows, works = _exchange(ids, rows, hi - lo, rank, world, group)
+    send_splits, recv_splits = _read_counts(_counts_by_owner(ids, hi - lo, world), world, group)
+    if send_splits[rank] != 0:
+        raise RuntimeError("sharded_spmm: own rows must not enter the exchange")
+    (recv_ids, recv_rows), works = _swap([ids, rows], send_splits, recv_splits, group)
     direct = out_slab is not None and out_slab.is_contiguous() and out_slab.dtype == matrix_local.dtype
     slab = own(out_slab) if direct else own()
     for w in works:

@@ -50,6 +50,12 @@ typedef void* gnnops_stream_t;
 int gnnops_version(void);
 const char* gnnops_last_error(void);
 
+/* Measurement aid for bench.py's roofline leg (no reference counterpart): `reads` sequential nontemporal read streams of
+ * `pieces` 16-B pieces each (src holds reads * pieces pieces) combined into ONE nontemporal write stream (dst: `pieces`
+ * pieces, or NULL for reads only). The rate of the 5 : 1 mix is what the memory system offers the config-2 segment
+ * reduction (5 source rows and the index per output row) on the box at hand. */
+int gnnops_diag_stream_mix(const void* src, void* dst, int64_t pieces, int reads, gnnops_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * dim_size discovery. torch_scatter computes `int(index.max()) + 1` when dim_size is None
  * (behind benchmark_scatter_add.py:18, benchmark_scatter_min.py:17). Writes max(index) (or -1 when
@@ -319,6 +325,11 @@ int gnnops_spspmm_expand(const int64_t* rowA, const int64_t* colA, const void* v
 int gnnops_rowptr_expand(const int32_t* rowptr, int64_t N, int64_t E, int64_t* index, gnnops_stream_t stream);
 int gnnops_sddmm(const int64_t* rows_a, const int64_t* rows_b, const void* a, const void* b, void* out,
                  int64_t nnz, int64_t D, int dtype, gnnops_stream_t stream);
+/* Destination-partitioned scatter over the GPUs of a node (BASELINE config 5; gnnops/dist.py): counts[g] = number of
+ * positions e with g * rows_per_owner <= index[e] < (g + 1) * rows_per_owner, g < owners <= 64 — what sizes the one
+ * exchange of the step (the only value the host reads back). counts: device int64[owners], zeroed here. */
+int gnnops_owner_counts(const int64_t* index, int64_t E, int64_t rows_per_owner, int owners, int64_t* counts,
+                        gnnops_stream_t stream);
 size_t gnnops_rowptr_workspace_bytes(int64_t N);
 int gnnops_rowptr_from_sorted(const int64_t* sorted_index, int64_t E, int64_t N, int32_t* rowptr,
                               void* workspace, size_t workspace_bytes, gnnops_stream_t stream);

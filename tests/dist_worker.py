@@ -27,28 +27,63 @@ class OracleLocal:
     """CPU stand-in for gnnops.dist.HipLocal (same contract), on numpy + the oracle: only the exchange logic of
     sharded_scatter(exchange="sparse") is under test here."""
 
-    def split(self, src, index, n_total, lo, hi, reduce, own_dense):
+    # ---- edge-list form (same contract as HipLocal.owner_counts / route_ready / route_begin / route)
+    def owner_counts(self, index, per, world):
+        return torch.from_numpy(np.bincount(index.numpy() // per, minlength=world).astype(np.int64))
+
+    def route_ready(self, src, lo, hi):
+        return src.dtype == torch.float32
+
+    def route_begin(self, src, index, lo, hi):
+        return (src, index, None)
+
+    def route(self, state, n_total, lo, hi, send_splits, rank):
+        src, index, _ = state
+        idx = index.numpy()
+        per = hi - lo
+        assert int((idx // per == rank).sum()) == send_splits[rank] and sum(send_splits) == len(idx)
+        remote = np.nonzero(idx // per != rank)[0]
+        order = np.argsort(idx[remote] // per, kind="stable")
+        pos = remote[order]
+        send_ids = torch.from_numpy(idx[pos].astype(np.int64))
+        send_rows = src[torch.from_numpy(pos)]
+
+        def own(out=None):
+            mine = np.nonzero(idx // per == rank)[0]
+            slab = out if out is not None else torch.empty((per, src.shape[1]), dtype=src.dtype)
+            slab.zero_()
+            slab.index_add_(0, torch.from_numpy(idx[mine] - lo), src[torch.from_numpy(mine)])
+            return slab
+
+        return own, send_ids, send_rows
+
+    # ---- compact form
+    def split(self, src, index, n_total, lo, hi, reduce, own_dense, want_arg=False):
         from oracle import oracle
 
         idx = index.numpy()
         uniq, inv = np.unique(idx, return_inverse=True)
         red = oracle.scatter(src.numpy(), inv.astype(np.int64), dim=0, dim_size=len(uniq), reduce=reduce)
-        red = red[0] if isinstance(red, tuple) else red
+        arg = None
+        if isinstance(red, tuple):
+            red, arg = red
         remote = (uniq < lo) | (uniq >= hi)
         ids = torch.from_numpy(uniq[remote].astype(np.int64))
         rows = torch.from_numpy(np.ascontiguousarray(red[remote]))
+        args = torch.from_numpy(np.ascontiguousarray(arg[remote])) if want_arg else None
         own_ids = torch.from_numpy((uniq[~remote] - lo).astype(np.int64))
         own_rows = torch.from_numpy(np.ascontiguousarray(red[~remote]))
+        own_args = torch.from_numpy(np.ascontiguousarray(arg[~remote])) if want_arg else None
 
         def own(out=None):
             if not own_dense:
-                return own_ids, own_rows
+                return own_ids, own_rows, own_args
             slab = out if out is not None else torch.empty((hi - lo, src.shape[1]), dtype=src.dtype)
             slab.zero_()
             slab[own_ids] = own_rows
             return slab
 
-        return own, ids, rows
+        return own, ids, rows, args
 
     def spmm_split(self, row, col, value, mat, n_total, lo, hi):
         from oracle import oracle
@@ -75,16 +110,20 @@ class OracleLocal:
         slab.index_add_(0, ids_local, rows)
         return slab
 
-    def combine(self, rows, ids_local, n_local, reduce):
+    def combine(self, rows, ids_local, n_local, reduce, want_arg=False):
         from oracle import oracle
 
         res = oracle.scatter(rows.numpy(), ids_local.numpy(), dim=0, dim_size=n_local, reduce=reduce)
+        if want_arg:
+            return torch.from_numpy(res[0]), torch.from_numpy(res[1])
         return torch.from_numpy(res[0] if isinstance(res, tuple) else res)
 
 
 def make_inputs(rank, world, n_total, e_local, d):
     g = torch.Generator().manual_seed(100 + rank)
     src = torch.rand(e_local, d, generator=g) * 2 - 1
+    if os.environ.get("GNNOPS_TEST_TIES") == "1":   # few distinct values: minima / maxima tie within and across ranks
+        src = torch.randint(-2, 3, (e_local, d), generator=g).float()
     idx = torch.randint(0, n_total, (e_local,), generator=g)
     idx[idx == 5] = 6  # global destination 5 receives nothing from anyone
     return src, idx
@@ -111,6 +150,10 @@ def run(rank, world, init_file, n_total, e_local, d, out_dir):
             res[r] = sharded_scatter(src, idx, n_total, r, local_scatter=oracle_local_scatter).numpy()
         for r in ("sum", "min", "max", "mean", "mul"):
             res["sparse_" + r] = sharded_scatter(src, idx, n_total, r, local=OracleLocal()).numpy()
+        res["compact_sum"] = sharded_scatter(src, idx, n_total, "sum", local=OracleLocal(), exchange="compact").numpy()
+        for r in ("min", "max"):
+            val, arg = sharded_scatter(src, idx, n_total, r, local=OracleLocal(), return_arg=True)
+            res["arg_" + r + "_val"], res["arg_" + r] = val.numpy(), arg.numpy()
         slab = torch.full((n_total // world, d), 7.0)
         got = sharded_scatter(src, idx, n_total, "sum", local=OracleLocal(), out_slab=slab)
         assert got is slab
@@ -141,6 +184,10 @@ def run_gpu(rank, world, init_file, n_total, e_local, d, out_dir):
         res = {}
         for r in ("sum", "min", "max", "mean", "mul"):
             res["sparse_" + r] = sharded_scatter(src, idx, n_total, r).cpu().numpy()
+        res["compact_sum"] = sharded_scatter(src, idx, n_total, "sum", exchange="compact").cpu().numpy()
+        for r in ("min", "max"):
+            val, arg = sharded_scatter(src, idx, n_total, r, return_arg=True)
+            res["arg_" + r + "_val"], res["arg_" + r] = val.cpu().numpy(), arg.cpu().numpy()
         slab = torch.full((n_total // world, d), 7.0, device="cuda")
         got = sharded_scatter(src, idx, n_total, "sum", out_slab=slab)
         assert got is slab

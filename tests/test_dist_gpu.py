@@ -1,5 +1,6 @@
-"""GPU parity of the per-rank pieces of gnnops.dist (HipLocal) — the split of one rank's edges into the own slab and the
-compact remote (id, row) lists, and the two ways the received lists are folded in — against the oracle, as if this GPU
+"""GPU parity of the per-rank pieces of gnnops.dist (HipLocal) — the owner counts, the routing of one rank's edges into the
+own slab and the per-owner (id, row) edge lists, the compact per-destination split (min / max / mul, with positions), and
+the two ways the received lists are folded in — against the oracle, as if this GPU
 were rank 1 of 3 (destinations both below and above its range). The exchange itself is covered on CPU (test_dist_cpu.py,
 gloo), by bench.py's one-rank RCCL rehearsal, and end to end by the last test here: gloo ranks sharing this box's one GPU."""
 import numpy as np
@@ -40,23 +41,56 @@ def test_split_matches_oracle(local, oracle, reduce, E, n_total, D):
     src, idx = _inputs(E, n_total, D, 11)
     lo, hi = n_total // 3, 2 * n_total // 3
     own_dense = reduce == "sum"
-    own, ids, rows = local.split(src.cuda(), idx.cuda(), n_total, lo, hi, reduce, own_dense)
+    want_arg = reduce in ("min", "max")
+    own, ids, rows, args = local.split(src.cuda(), idx.cuda(), n_total, lo, hi, reduce, own_dense, want_arg=want_arg)
     exp = oracle.scatter(src.numpy(), idx.numpy(), dim=0, dim_size=n_total, reduce=reduce)
-    exp = exp[0] if isinstance(exp, tuple) else exp
+    earg = None
+    if isinstance(exp, tuple):
+        exp, earg = exp
     touched = np.bincount(idx.numpy(), minlength=n_total) > 0
     remote = touched.copy()
     remote[lo:hi] = False
     assert np.array_equal(ids.cpu().numpy(), np.nonzero(remote)[0])
     assert np.array_equal(rows.cpu().numpy(), exp[remote])  # sequential order inside a destination: bit-exact
+    if want_arg:
+        assert np.array_equal(args.cpu().numpy(), earg[remote])   # local position of each extremum
     part = own()
     if own_dense:
         assert np.array_equal(part.cpu().numpy(), exp[lo:hi])
         buf = torch.full((hi - lo, D), 3.0, device="cuda")
         assert own(buf) is buf and np.array_equal(buf.cpu().numpy(), exp[lo:hi])
     else:
-        own_ids, own_rows = part
+        own_ids, own_rows, own_args = part
         assert np.array_equal(own_ids.cpu().numpy(), np.nonzero(touched[lo:hi])[0])
         assert np.array_equal(own_rows.cpu().numpy(), exp[lo:hi][touched[lo:hi]])
+        if want_arg:
+            assert np.array_equal(own_args.cpu().numpy(), earg[lo:hi][touched[lo:hi]])
+
+
+@pytest.mark.parametrize("E,n_total,D", [(50000, 3000, 128), (7000, 9000, 16), (0, 3000, 4), (30000, 1200, 64)])
+def test_owner_counts_and_route_match_oracle(local, oracle, E, n_total, D):
+    """The edge-list form of the exchange (sums): owner counts, the windowed partition, the remote (id, row) pairs grouped
+    by owner in source order, and the own slab — as rank 1 of 3."""
+    src, idx = _inputs(E, n_total, D, 13)
+    world, rank = 3, 1
+    per = n_total // world
+    lo, hi = rank * per, (rank + 1) * per
+    counts = local.owner_counts(idx.cuda(), per, world)
+    exp_counts = np.bincount(idx.numpy() // per, minlength=world)
+    assert counts.cpu().tolist() == exp_counts.tolist()
+    assert local.route_ready(src.cuda(), lo, hi)
+    state = local.route_begin(src.cuda(), idx.cuda(), lo, hi)
+    own, send_ids, send_rows = local.route(state, n_total, lo, hi, exp_counts.tolist(), rank)
+    owner = idx.numpy() // per
+    remote = np.nonzero(owner != rank)[0]
+    pos = remote[np.argsort(owner[remote], kind="stable")]
+    assert np.array_equal(send_ids.cpu().numpy(), idx.numpy()[pos])
+    assert np.array_equal(send_rows.cpu().numpy(), src.numpy()[pos])
+    mine = owner == rank
+    exp = oracle.scatter(src.numpy()[mine], idx.numpy()[mine] - lo, dim=0, dim_size=per, reduce="sum")
+    assert np.array_equal(own().cpu().numpy(), exp)              # same order as the sequential loop: bit-exact
+    buf = torch.full((per, D), 3.0, device="cuda")
+    assert own(buf) is buf and np.array_equal(buf.cpu().numpy(), exp)
 
 
 @pytest.mark.parametrize("dname", ["f32", "bf16"])

@@ -39,6 +39,10 @@ def check(world, n_total, e_local, d):
             assert np.array_equal(got["sparse_sum_out"], got["sparse_sum"])
             exp = oracle.scatter(src, idx, dim=0, dim_size=n_total, reduce="sum")
             np.testing.assert_allclose(got["dense_sum"], exp[lo:hi], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(got["compact_sum"], exp[lo:hi], rtol=1e-5, atol=1e-5)
+            for r in ("min", "max"):   # (value, index) pair reduction: arg = global (rank-major) position
+                ev, ea = oracle.scatter(src, idx, dim=0, dim_size=n_total, reduce=r)
+                assert np.array_equal(got["arg_" + r + "_val"], ev[lo:hi]) and np.array_equal(got["arg_" + r], ea[lo:hi]), r
             np.testing.assert_allclose(got["spmm"], exp_spmm[lo:hi], rtol=1e-5, atol=1e-5)
     print(f"ok world={world} n_total={n_total} e_local={e_local} d={d}", flush=True)
 
