@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""One parametrised counterpart of the reference's 17 op_bm_scripts/benchmark_*.py.
+"""The reference's 17 op_bm_scripts/benchmark_*.py as ONE spec-driven runner on the gfx950 kernels.
 
-Same protocol as the reference: inputs built on the device, `op_*` body handed to
-torch.utils.benchmark.Timer(stmt, setup, globals).timeit(n) — 2 warm-ups, one synchronised block of n
-calls, mean seconds per call — one CSV row per (op, shape, dim, reduce factor). The op bodies are the
-reference's, calling the same names (`torch_scatter.scatter_add`, `torch.index_select`, ...) — which resolve
-to the gfx950 kernels through the shim packages and `gnnops.install()`.
+Two modes:
 
-    python benchmark_ops.py --ops scatter_add,index_select --point ref_max      # the reference's largest published shapes
-    python benchmark_ops.py --ops all --point ref_min --csv out.csv
+  --sweep ref    every script's own loops (reduce factors x sparsities x the linspace of lengths x dims, in the reference's
+                 order), inputs built on the device exactly as the script builds them, the script's `op_*` body handed to
+                 torch.utils.benchmark.Timer(stmt, globals) with the script's protocol (`timeit(n)` or `blocked_autorange`),
+                 and ONE CSV PER OP with the reference's exact column names, row formatting and file name
+                 (mem_prof_data/<op>_small.csv, mem_prof_data/<op>.csv, new_data/<op>.csv, datatest/native_sort.csv via
+                 DataWriter) — comparable row for row with the CSVs the reference ships. `--limit K` keeps K evenly spaced
+                 points of each sweep, `--num N` changes the number of lengths, `--runs n` the calls per measurement.
+                 The spec of each script cites the reference lines it restates.
+  --sweep point  (default) one table over all ops at the reference's largest / smallest published shape (`--point`), with
+                 algorithmic GB/s and the A100-40GB numbers of BASELINE.md beside ours.
 
-The A100-40GB numbers printed beside ours are the reference's own (file:line given there).
+The op bodies are the reference's, calling the same names (`torch_scatter.scatter_add`, `torch.index_select`, ...) — they
+resolve to the gfx950 kernels through the shim packages and `gnnops.install()`; the two "fused" bodies are the reference's
+TorchScript text, rewritten by gnnops/jit.py; the transpose body is the reference's `.transpose(0, 1).contiguous()`.
+
+    python benchmark_ops.py --sweep ref --ops scatter_add,native_sort --limit 8 --out /tmp/csv
+    python benchmark_ops.py --ops all --point ref_max --csv out.csv
 """
 import argparse
 import csv
@@ -21,59 +30,543 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
+import numpy as np
 import torch
 import torch.utils.benchmark as benchmark
 
-import gnnops
-import torch_scatter
-import torch_sparse
-from graph_benchmark.benchmark.util import setup_seed
-
-# ---- op bodies: the reference's, verbatim in meaning (file:line under the reference root) ----------------------
+# ---- op bodies: the reference's (file:line under the reference root) --------------------------------------------
 def op_scatter_add(src, idx, dim):            # benchmark_scatter_add.py:15-19
+    import torch_scatter
     return torch_scatter.scatter_add(src, idx, dim=dim)
 def op_native_scatter_add_(src, idx, dim):    # benchmark_scatter_add.py:22-25
     temp = torch.zeros_like(src)
     temp.scatter_add_(dim, idx, src)
 def op_scatter_min(src, idx, dim):            # benchmark_scatter_min.py:15-18
+    import torch_scatter
     return torch_scatter.scatter_min(src, idx, dim)
 def op_scatter_max(src, idx, dim):            # benchmark_scatter_max.py:15-18
+    import torch_scatter
     return torch_scatter.scatter_max(src, idx, dim)
 def op_scatter_mean(src, idx, dim):           # benchmark_scatter_mean.py:15-18
+    import torch_scatter
     return torch_scatter.scatter_mean(src, idx, dim)
 def op_native_scatter_multiply_(src, idx):    # benchmark_scatter_multiply.py:42-45
     temp = torch.zeros_like(src)
     temp.scatter_(-1, idx, src, reduce="multiply")
 def op_native_index_select(input, dim, index):  # benchmark_native_index_select.py:12-15
-    return torch.index_select(input, dim, index)
+    return torch.index_select(input=input, dim=dim, index=index)
 def op_native_index_add_(input, dim, index, source):  # benchmark_native_index_add_.py:13-16
     input.index_add_(dim, index, source)
 def op_native_gather(input, dim, index):      # benchmark_native_gather.py:14-17
     return torch.gather(input, dim, index)
 def op_native_sort(input, dim, stable):       # benchmark_native_sort.py:28-30
-    return torch.sort(input, dim=dim, stable=stable)
+    return torch.sort(input=input, dim=dim, stable=stable)
 def op_native_smm(matA, matB):                # benchmark_sparse_spmm.py:12-14 / benchmark_sparse_spspmm.py:12-14
     return torch.sparse.mm(matA, matB)
 def op_sparse_coalesce(index, value, m, n):   # benchmark_sparse_coalesce.py:35-37
+    import torch_sparse
     return torch_sparse.coalesce(index=index, value=value, m=m, n=n)
+def op_native_coalesce(mat):                  # benchmark_sparse_coalesce.py:40-42
+    mat.coalesce()
 def op_native_transpose(matA):                # benchmark_sparse_transpose.py:13-16
-    return gnnops.transpose_contiguous(matA)
-def op_fused_index_select_reduce(input, dim, index):     # benchmark_fused_index_select_reduce.py:12-20
-    return gnnops.index_select_sum(input, dim, index)
-def op_unfused_index_select_reduce(input, dim, index):
-    return torch.index_select(input, dim, index).float().sum()
-def op_fused_index_add_reduce(input, dim, index, other):  # benchmark_fused_index_add_reduce.py:12-20
-    return gnnops.index_add_select_sum(input, dim, index, other)
+    return torch.transpose(matA, 0, 1).contiguous()
+def gelu_select(input, dim: int, index):      # benchmark_fused_index_select_reduce.py:12-20 (`fused_gelu` scripted, `gelu` eager)
+    out = torch.index_select(input, dim, index).sum()
+    return out
+def gelu_add(input, dim: int, index, other):  # benchmark_fused_index_add_reduce.py:12-20
+    out = torch.index_add(input, dim, index, other)
+    return torch.index_select(out, dim, index).sum(dim)
 def op_native_addmm(input, mat1, mat2):       # benchmark_native_addmm.py:13-16
-    return torch.addmm(input, mat1, mat2)
+    return torch.addmm(input=input, mat1=mat1, mat2=mat2)
 def op_native_matmul(input, other):           # benchmark_native_matmul.py:13-16
-    return torch.matmul(input, other)
+    return torch.matmul(input=input, other=other)
 
 
 DEV = "cuda"
 H = torch.float16
+MEM_COLS = ["Input size", "Sparsity", "Total elements", "Input memory", "Total Memory"]
 
 
+def lengths(lo, hi, num):
+    """`[int(math.sqrt(x)) for x in np.linspace(lo, hi, num=num).tolist()]` — every length sweep of the reference."""
+    return [int(math.sqrt(x)) for x in np.linspace(lo, hi, num=num).tolist()]
+
+
+def _dropout(t, p):
+    return torch.nn.functional.dropout(t, p=p, training=True, inplace=False)
+
+
+def _mb(*tensors):
+    return sum(t.element_size() * t.numel() for t in tensors) / 1000000
+
+
+def _reserved_mb():
+    from graph_benchmark.benchmark.util import get_reserved_in_mb
+
+    return get_reserved_in_mb()
+
+
+def _t(bm):  # "median(iqr)" cell of the reference's CSVs
+    return str(bm.median) + "(" + str(bm.iqr) + ")"
+
+
+class Spec:
+    """One reference script: its loops (`sweep`), its inputs (`build`), its timed statements and its CSV."""
+    script = ""       # reference file
+    csv = ""          # path the reference writes, relative to the working directory
+    columns = ()
+    mode = ("timeit", 100)   # or ("autorange", min_run_time or None)
+    num = 100         # lengths in the sweep
+
+    def sweep(self, num):
+        raise NotImplementedError
+
+    def run_point(self, p, measure):
+        """Build the inputs of sweep point p, time the statements with `measure(stmt, globals)`, return the CSV row."""
+        raise NotImplementedError
+
+
+def _square_shapes(lo, hi, num):
+    return [(L, L) for L in lengths(lo, hi, num)]
+
+
+class ScatterSpec(Spec):
+    """benchmark_scatter_{add,min,max,mean}.py:34-46,60-63 (loops), :67-94 (inputs), :97-142 (timers, row), :153-165 (CSV)."""
+    lo, hi = 50_000, 2_000_000    # the scripts' current sweep; the published CSVs used 1_500_000 .. 45_000_000 (:40 comment)
+
+    def __init__(self, op, fn, native=None):
+        self.op, self.fn, self.native = op, fn, native
+        self.script = f"benchmark_{op}.py"
+        self.csv = f"mem_prof_data/{op}_small.csv"
+        self.columns = ["Reduce factor, shape, dim"] + MEM_COLS + ["GPU clock time py geo (IQR)"] + (
+            ["GPU clock time native (IQR)"] if native else [])
+
+    def sweep(self, num):
+        for reduce_f in [1, 2, 4, 8]:
+            for sparsity in [0]:
+                for src_dims in _square_shapes(self.lo, self.hi, num):
+                    for dim in [0, 1]:
+                        yield dict(reduce_f=reduce_f, sparsity=sparsity, src_dims=src_dims, dim=dim)
+
+    def run_point(self, p, measure):
+        src_dims, dim = p["src_dims"], p["dim"]
+        max_idx = int(src_dims[0] / p["reduce_f"])
+        src = torch.rand(size=src_dims, device=DEV, dtype=H, requires_grad=False)
+        idx = torch.randint(high=max_idx, size=src_dims, device=DEV, dtype=torch.int64, requires_grad=False)
+        src = _dropout(src, p["sparsity"])
+        total_elts = idx.numel() + src.numel()
+        input_mem = _mb(idx, src)
+        g = {"src": src, "idx": idx, "dim": dim, self.fn.__name__: self.fn}
+        bm = measure(f"{self.fn.__name__}(src, idx, dim)", g)
+        mem = _reserved_mb()
+        row = [str(p["reduce_f"]) + " " + ("LS" if len(src_dims) == 1 else "square") + " " + str(dim), str(src_dims),
+               p["sparsity"], total_elts, input_mem, mem, _t(bm)]
+        if self.native:
+            g[self.native.__name__] = self.native
+            row.append(_t(measure(f"{self.native.__name__}(src, idx, dim)", g)))
+        return row
+
+
+class MultiplySpec(Spec):
+    """benchmark_scatter_multiply.py:52-59 (shapes, sparsities), :71-117 (inputs, blocked_autorange), :140-169 (row, CSV)."""
+    script, csv = "benchmark_scatter_multiply.py", "new_data/scatter_multiply.csv"
+    columns = ["Reduce factor, shape", "Input size (>95% mem util)*", "Sparsity", "GPU clock time"]
+    mode = ("autorange", None)
+
+    def sweep(self, num):
+        tshapes = [(int(1600384000 * 1.5),), (int(40000 * 1.2), int(40000 * 1.2))]
+        for reduce_f in [1, 2, 4, 8]:
+            for sparsity in [0, 0.5, 0.9, 0.99]:
+                for src_dims in tshapes:
+                    yield dict(reduce_f=reduce_f, sparsity=sparsity, src_dims=src_dims)
+
+    def run_point(self, p, measure):
+        src_dims = p["src_dims"]
+        src = torch.rand(size=src_dims, device=DEV, dtype=torch.float32, requires_grad=False)
+        idx = torch.randint(high=int(src_dims[0] / p["reduce_f"]), size=src_dims, device=DEV, dtype=torch.int64)
+        src = _dropout(src, p["sparsity"])
+        bm = measure("op_native_scatter_multiply_(src, idx)",
+                     {"src": src, "idx": idx, "op_native_scatter_multiply_": op_native_scatter_multiply_})
+        return [str(p["reduce_f"]) + " " + ("LS" if len(src_dims) == 1 else "square"), str(src_dims), p["sparsity"],
+                "%g" % round(bm.median, 3)]
+
+
+class IndexSelectSpec(Spec):
+    """benchmark_native_index_select.py:38-45 (lengths), :59-67 (loops), :70-90 (inputs), :93-139 (timer, row),
+    :147-157 (CSV, commented out in the script: the columns are its own)."""
+    script, csv = "benchmark_native_index_select.py", "mem_prof_data/native_index_select.csv"
+    columns = ["Input dims, index dim, reduce factor (RF)"] + MEM_COLS + ["GPU clock time (IQR)"]
+    mode, num = ("timeit", 1), 10
+    lo, hi = 7_500_000, 200_000_000
+
+    def sweep(self, num):
+        for sparsity in [0]:
+            for tshape in _square_shapes(self.lo, self.hi, num):
+                for dim in [0, 1, 2]:
+                    for rf in [1, 2, 4, 8]:
+                        if dim >= len(tshape):
+                            continue
+                        yield dict(sparsity=sparsity, tshape=tshape, dim=dim, rf=rf)
+
+    def _inputs(self, p):
+        tshape, dim = p["tshape"], p["dim"]
+        input = _dropout(torch.rand(size=tshape, device=DEV, dtype=H, requires_grad=False), p["sparsity"])
+        index = torch.randint(low=0, high=input.shape[dim], size=(int(input.shape[dim] / p["rf"]),), device=DEV)
+        return input, index
+
+    def run_point(self, p, measure):
+        input, index = self._inputs(p)
+        total_elts = input.numel() + index.numel()
+        input_mem = _mb(input, index)
+        bm = measure("op_native_index_select(input, dim, index)",
+                     {"input": input, "dim": p["dim"], "index": index, "op_native_index_select": op_native_index_select})
+        return [str(len(p["tshape"])) + "; " + str(p["dim"]) + "; " + str(p["rf"]), str(p["tshape"]), p["sparsity"],
+                total_elts, input_mem, _reserved_mb(), _t(bm)]
+
+
+class FusedSelectSpec(IndexSelectSpec):
+    """benchmark_fused_index_select_reduce.py:43-48 (100 lengths, 100 runs), :60-67 (loops), :93-117 (the SCRIPTED body,
+    then the eager one), :167-178 (CSV)."""
+    script, csv = "benchmark_fused_index_select_reduce.py", "mem_prof_data/fused_index_select_reduce.csv"
+    columns = ["Input dims, index dim, reduce factor (RF)"] + MEM_COLS + ["GPU clock time (fuse) (IQR)",
+                                                                        "GPU clock time (no fuse) (IQR)"]
+    mode, num = ("timeit", 100), 100
+
+    def run_point(self, p, measure):
+        input, index = self._inputs(p)
+        total_elts = input.numel() + index.numel()
+        input_mem = _mb(input, index)
+        g = {"input": input, "dim": p["dim"], "index": index, "fused_gelu": scripted(gelu_select), "gelu": gelu_select}
+        bm = measure("fused_gelu(input, dim, index)", g)
+        mem = _reserved_mb()
+        bm_no = measure("gelu(input, dim, index)", g)
+        return [str(len(p["tshape"])) + "; " + str(p["dim"]) + "; " + str(p["rf"]), str(p["tshape"]), p["sparsity"],
+                total_elts, input_mem, mem, _t(bm), _t(bm_no)]
+
+
+class FusedAddSpec(Spec):
+    """benchmark_fused_index_add_reduce.py:43-48, :60-63 (loops), :70-100 (inputs: index of input.shape[dim] entries,
+    other = input.clone()), :101-160 (scripted, then eager; row with RF "1"), :181-192 (CSV)."""
+    script, csv = "benchmark_fused_index_add_reduce.py", "mem_prof_data/fused_index_add_reduce.csv"
+    columns = FusedSelectSpec.columns
+    lo, hi = 7_500_000, 200_000_000
+
+    def sweep(self, num):
+        for sparsity in [0]:
+            for tshape in _square_shapes(self.lo, self.hi, num):
+                for dim in [0, 1, 2]:
+                    if dim >= len(tshape):
+                        continue
+                    yield dict(sparsity=sparsity, tshape=tshape, dim=dim)
+
+    def run_point(self, p, measure):
+        tshape, dim = p["tshape"], p["dim"]
+        input = _dropout(torch.rand(size=tshape, device=DEV, dtype=H, requires_grad=False), p["sparsity"])
+        index = torch.randint(low=0, high=input.shape[dim], size=(int(input.shape[dim]),), device=DEV)
+        other = torch.clone(input)
+        total_elts = input.numel() + index.numel()
+        input_mem = _mb(input, index)
+        g = {"input": input, "dim": dim, "index": index, "other": other, "fused_gelu": scripted(gelu_add), "gelu": gelu_add}
+        bm = measure("fused_gelu(input, dim, index, other)", g)
+        mem = _reserved_mb()
+        bm_no = measure("gelu(input, dim, index, other)", g)
+        return [str(len(tshape)) + "; " + str(dim) + "; " + str(1), str(tshape), p["sparsity"], total_elts, input_mem, mem,
+                _t(bm), _t(bm_no)]
+
+
+class IndexAddSpec(Spec):
+    """benchmark_native_index_add_.py:39-44, :59-63 (dim 1 only), :66-100 (inputs), :101-140 (timer, row), :148-158 (CSV)."""
+    script, csv = "benchmark_native_index_add_.py", "mem_prof_data/native_index_add_.csv"
+    columns = ["Input dims, index dim", "Input size", "Sparsity", "Total elements", "Input memory", "TOtal Memory",
+               "GPU clock time (IQR)"]
+    mode, num = ("timeit", 1), 10
+
+    def sweep(self, num):
+        for sparsity in [0]:
+            for tshape in _square_shapes(2_500_000, 100_000_000, num):
+                for dim in [1]:
+                    yield dict(sparsity=sparsity, tshape=tshape, dim=dim)
+
+    def run_point(self, p, measure):
+        tshape, dim = p["tshape"], p["dim"]
+        input = torch.rand(size=tshape, device=DEV, dtype=H, requires_grad=False)
+        source = torch.rand(size=tshape, device=DEV, dtype=H, requires_grad=False)
+        index = torch.randint(low=0, high=source.shape[dim], size=(source.shape[dim],), dtype=torch.int64, device=DEV)
+        source = _dropout(source, p["sparsity"])
+        total_elts = input.numel() + source.numel() + index.numel()
+        input_mem = _mb(input, index, source)
+        bm = measure("op_native_index_add_(input, dim, index, source)",
+                     {"input": input, "dim": dim, "index": index, "source": source, "op_native_index_add_": op_native_index_add_})
+        return [str(len(tshape)) + "; " + str(dim), str(tshape), p["sparsity"], total_elts, input_mem, _reserved_mb(), _t(bm)]
+
+
+class GatherSpec(Spec):
+    """benchmark_native_gather.py:39-48, :66-73 (loops), :76-104 (inputs), :105-142 (timer, row), :150-160 (CSV)."""
+    script, csv = "benchmark_native_gather.py", "mem_prof_data/native_gather.csv"
+    columns = ["Input dims"] + MEM_COLS + ["GPU clock time (IQR)"]
+    mode, num = ("timeit", 1), 10
+
+    def sweep(self, num):
+        for sparsity in [0]:
+            for tshape in _square_shapes(1_500_000, 40_000_000, num):
+                for dim in [0, 1, 2]:
+                    if dim >= len(tshape):
+                        continue
+                    yield dict(sparsity=sparsity, tshape=tshape, dim=dim)
+
+    def run_point(self, p, measure):
+        tshape, dim = p["tshape"], p["dim"]
+        input = torch.rand(size=tshape, device=DEV, dtype=H, requires_grad=False)
+        index = torch.randint(low=0, high=input.shape[dim], size=input.shape, dtype=torch.int64, device=DEV)
+        total_elts = input.numel() + index.numel()
+        input_mem = _mb(input, index)
+        input = _dropout(input, p["sparsity"])
+        bm = measure("op_native_gather(input, dim, index)",
+                     {"input": input, "dim": dim, "index": index, "op_native_gather": op_native_gather})
+        return [str(len(tshape)) + "; " + str(dim), str(tshape), p["sparsity"], total_elts, input_mem, _reserved_mb(), _t(bm)]
+
+
+class SortSpec(Spec):
+    """benchmark_native_sort.py:37-48 (shapes, sparsities, DataWriter), :66-69 (loops), :84-125 (inputs,
+    blocked_autorange(min_run_time=1)), :127-140 (DataWriter rows, ./datatest/native_sort.csv)."""
+    script, csv = "benchmark_native_sort.py", "datatest/native_sort.csv"
+    columns = ["Input dims, sort dim, stable", "Input size (>95% mem util)*", "Sparsity", "GPU clock time"]
+    mode = ("autorange", 1)
+    uses_datawriter = True
+
+    def sweep(self, num):
+        tshapes = [(int(1600384000 * 0.5),), (int(40000 * 0.5),) * 2, (int(2000 * 0.4),) * 3]
+        for sparsity in [0, 0.5, 0.9, 0.99]:
+            for tshape in tshapes:
+                for dim in [0, 1, 2]:
+                    for stable in [True, False]:
+                        if dim >= len(tshape):
+                            continue
+                        yield dict(sparsity=sparsity, tshape=tshape, dim=dim, stable=stable)
+
+    def run_point(self, p, measure):
+        input = _dropout(torch.rand(size=p["tshape"], device=DEV, dtype=torch.float32, requires_grad=False), p["sparsity"])
+        m0 = measure("op_native_sort(input, dim, stable)",
+                     {"input": input, "dim": p["dim"], "stable": p["stable"], "op_native_sort": op_native_sort})
+        # DataWriter.add_entry(params_lst, tshape, sparsity, bm_val): ";"-joined params, str(tshape)
+        return [";".join([str(len(p["tshape"])), str(p["dim"]), str(p["stable"])]), str(p["tshape"]), p["sparsity"], m0.median]
+
+
+class SparseMMSpec(Spec):
+    """benchmark_sparse_spmm.py / benchmark_sparse_spspmm.py:28-33, :61-64 (loops), :66-100 (inputs), :103-140 (timer, row
+    with " (" before the IQR), :151-162 (CSV)."""
+    mode, num = ("timeit", 1), 10
+    columns = ["Input dims", "Input size", "Sparsities (matA, matB)", "Total elements", "Input memory", "Total Memory",
+               "GPU clock time (IQR)"]
+
+    def __init__(self, op, sparsity, both_sparse):
+        self.script, self.csv = f"benchmark_{op}.py", f"mem_prof_data/{op}.csv"
+        self.sparsity, self.both_sparse = sparsity, both_sparse
+
+    def sweep(self, num):
+        for sparsity_A in [self.sparsity]:
+            for sparsity_B in [self.sparsity]:
+                for L in lengths(2_000_000, 50_000_000, num):
+                    yield dict(sparsity_A=sparsity_A, sparsity_B=sparsity_B, tshape=[(L, L), (L, L)])
+
+    def run_point(self, p, measure):
+        tshape = p["tshape"]
+        matA = _dropout(torch.rand(size=tshape[0], device=DEV, dtype=torch.float32, requires_grad=False), p["sparsity_A"])
+        matB = _dropout(torch.rand(size=tshape[1], device=DEV, dtype=torch.float32, requires_grad=False), p["sparsity_B"])
+        matA = matA.to_sparse()
+        if self.both_sparse:
+            matB = matB.to_sparse()
+        total_elts = matA.numel() + matB.numel()
+        input_mem = (matA.element_size() * matA.numel() + matB.element_size() * matB.numel()) / 1000000
+        bm = measure("op_native_smm(matA, matB)", {"matA": matA, "matB": matB, "op_native_smm": op_native_smm})
+        return [str(len(tshape)), str(tshape), str(p["sparsity_A"]) + " ; " + str(p["sparsity_B"]), total_elts, input_mem,
+                _reserved_mb(), str(bm.median) + " (" + str(bm.iqr) + ")"]
+
+
+class CoalesceSpec(Spec):
+    """benchmark_sparse_coalesce.py:51-59 (shapes, sparsities), :70-73 (loops), :82-166 (inputs: duplicated entries, only the
+    index shuffled), :174-211 (two blocked_autorange timers), :218-241 (row "ours (native)", CSV)."""
+    script, csv = "benchmark_sparse_coalesce.py", "new_data/sparse_coalesce.csv"
+    columns = ["Reduce factor", "Input size (>95% mem util)*", "Sparsity", "GPU clock time"]
+    mode = ("autorange", None)
+
+    def sweep(self, num):
+        tshapes = [(int(4000 * 250000 * 0.12), 1), (int(4000 * 3), int(4000 * 3))]
+        for sparsity in [0.5, 0.9, 0.99]:
+            for tshape in tshapes:
+                for reduce_factor in [1, 2, 4, 8]:
+                    yield dict(sparsity=sparsity, tshape=tshape, reduce_factor=reduce_factor)
+
+    def run_point(self, p, measure):
+        rf = p["reduce_factor"]
+        mat = _dropout(torch.rand(size=p["tshape"], device=DEV, dtype=torch.float32, requires_grad=False), p["sparsity"])
+        m, n = mat.shape[0] * rf, mat.shape[1] * rf
+        mat = mat.to_sparse()
+        index_, value_ = mat.indices(), mat.values()
+        index, value = index_, value_
+        if rf > 1:
+            index = torch.cat((index_,) * rf, dim=1)
+            value = torch.cat((value_,) * rf)
+            index = index.index_select(1, torch.randperm(index.shape[1], device=DEV))
+        del mat
+        mat = torch.sparse_coo_tensor(index, value, (m, n))
+        bm = measure("op_sparse_coalesce(index, value, m, n)",
+                     {"index": index, "value": value, "m": m, "n": n, "op_sparse_coalesce": op_sparse_coalesce})
+        bm_native = measure("op_native_coalesce(mat)", {"mat": mat, "op_native_coalesce": op_native_coalesce})
+        return [str(rf), str(p["tshape"]), str(p["sparsity"]), str(bm.median) + " (" + str(bm_native.median) + ")"]
+
+
+class TransposeSpec(Spec):
+    """benchmark_sparse_transpose.py:22-28, :44-47 (loops), :49-75 (inputs; the measured sparsity replaces the loop variable,
+    as in the script), :78-108 (timer, row), :119-129 (CSV)."""
+    script, csv = "benchmark_sparse_transpose.py", "mem_prof_data/sparse_transpose.csv"
+    columns = ["Input Shape", "Input size", "Sparsities (matA)", "Total elements", "Input memory", "Total memory",
+               "GPU clock time (IQR)"]
+    mode, num = ("timeit", 1), 10
+
+    def sweep(self, num):
+        state = {"sparsity": 0.995}   # the script overwrites `sparsity` with the measured value inside the loop
+        for tshape in _square_shapes(4_000_000, 50_000_000, num):
+            yield dict(tshape=tshape, state=state)
+
+    def run_point(self, p, measure):
+        tshape, state = p["tshape"], p["state"]
+        matA = _dropout(torch.rand(size=tshape, device=DEV, dtype=H, requires_grad=False), state["sparsity"])
+        state["sparsity"] = float((torch.numel(matA) - torch.count_nonzero(matA)) / torch.numel(matA))
+        total_elts = matA.numel()
+        input_mem = (+matA.element_size() * matA.numel()) / 1000000
+        bm = measure("op_native_transpose(matA)", {"matA": matA, "op_native_transpose": op_native_transpose})
+        return ["LS" if tshape[1] == 1 else "Square", str(tshape), str(state["sparsity"]), total_elts, input_mem,
+                _reserved_mb(), _t(bm)]
+
+
+class GemmSpec(Spec):
+    """benchmark_native_addmm.py:23-38 / benchmark_native_matmul.py:23-37 (lengths, shapes), loops :55-58 / :54-56, inputs
+    :63-100 / :59-88, timer + row :101-140 / :89-120, CSV :151-162 / :128-139."""
+    mode, num = ("timeit", 100), 100
+
+    def __init__(self, op, n_mats, fn, sparsity_label):
+        self.script, self.csv = f"benchmark_{op}.py", f"mem_prof_data/{op}.csv"
+        self.n_mats, self.fn = n_mats, fn
+        self.columns = ["Input dims", "Input size", sparsity_label, "Total elements", "Input memory", "Total Memory",
+                        "GPU clock time (IQR)"]
+
+    def sweep(self, num):
+        for L in lengths(2_500_000, 66_666_667, num):
+            yield dict(tshape=[(L, L)] * self.n_mats)
+
+    def run_point(self, p, measure):
+        tshape = p["tshape"]
+        mats = [torch.rand(size=s, device=DEV, dtype=H, requires_grad=False) for s in tshape]
+        total_elts = sum(m.numel() for m in mats)
+        input_mem = _mb(*mats)
+        mats = [_dropout(m, 0) for m in mats]
+        if self.n_mats == 3:
+            g = {"input": mats[0], "matA": mats[1], "matB": mats[2], "op_native_addmm": op_native_addmm}
+            bm = measure("op_native_addmm(input, matA, matB)", g)
+        else:
+            g = {"input": mats[0], "other": mats[1], "op_native_matmul": op_native_matmul}
+            bm = measure("op_native_matmul(input, other)", g)
+        return [str(len(tshape)), str(tshape), " ; ".join(["0"] * self.n_mats), total_elts, input_mem, _reserved_mb(), _t(bm)]
+
+
+_scripted = {}
+
+
+def scripted(fn):
+    """`@torch.jit.script` of the reference's body text (after gnnops.install(): rewritten to the fused kernels)."""
+    if fn not in _scripted:
+        _scripted[fn] = torch.jit.script(fn)
+    return _scripted[fn]
+
+
+SPECS = {
+    "scatter_add": ScatterSpec("scatter_add", op_scatter_add, op_native_scatter_add_),
+    "scatter_min": ScatterSpec("scatter_min", op_scatter_min),
+    "scatter_max": ScatterSpec("scatter_max", op_scatter_max),
+    "scatter_mean": ScatterSpec("scatter_mean", op_scatter_mean),
+    "scatter_multiply": MultiplySpec(),
+    "native_index_select": IndexSelectSpec(),
+    "native_index_add_": IndexAddSpec(),
+    "native_gather": GatherSpec(),
+    "native_sort": SortSpec(),
+    "sparse_spmm": SparseMMSpec("sparse_spmm", 0.999, False),
+    "sparse_spspmm": SparseMMSpec("sparse_spspmm", 0.995, True),
+    "sparse_coalesce": CoalesceSpec(),
+    "sparse_transpose": TransposeSpec(),
+    "fused_index_select_reduce": FusedSelectSpec(),
+    "fused_index_add_reduce": FusedAddSpec(),
+    "native_addmm": GemmSpec("native_addmm", 3, op_native_addmm, "Sparsities (input, matA, matB)"),
+    "native_matmul": GemmSpec("native_matmul", 2, op_native_matmul, "Sparsities (input, other)"),
+}
+
+
+def spec_header(name):
+    """(csv path, column names) the reference writes for this script — checked against tests/golden/csv_headers.json."""
+    s = SPECS[name]
+    return s.csv, list(s.columns)
+
+
+def _measure_factory(mode, runs_override):
+    kind, arg = mode
+
+    def measure(stmt, g):
+        t = benchmark.Timer(stmt=stmt, globals=g)
+        if kind == "timeit":
+            return t.timeit(runs_override or arg)
+        return t.blocked_autorange(min_run_time=arg) if arg is not None else t.blocked_autorange()
+
+    return measure
+
+
+def run_sweep(name, out_dir, num=None, limit=None, runs=None, verbose=True):
+    """Run one reference script's sweep and write its CSV under out_dir; returns the path."""
+    import pandas as pd
+
+    from graph_benchmark.benchmark.util import empty_cache, setup_seed
+
+    spec = SPECS[name]
+    setup_seed(42)
+    points = list(spec.sweep(num or spec.num))
+    if limit and limit < len(points):
+        keep = sorted({round(i * (len(points) - 1) / (limit - 1)) for i in range(limit)}) if limit > 1 else [len(points) - 1]
+        points = [points[i] for i in keep]
+    measure = _measure_factory(spec.mode, runs)
+    rows = []
+    for counter, p in enumerate(points):
+        empty_cache()
+        rows.append(spec.run_point(p, measure))
+        if verbose:
+            print(f"{name}: done with {counter} {rows[-1][:2]} -> {rows[-1][-1]}", flush=True)
+    path = os.path.join(out_dir, spec.csv)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    if getattr(spec, "uses_datawriter", False):
+        from graph_benchmark.benchmark.DataWriter import DataWriter
+
+        dw = DataWriter(op_name=name, param_names=spec.columns[0])
+        for r in rows:
+            dw.add_entry(params_lst=r[0].split(";"), tshape=r[1], sparsity=r[2], bm_val=r[3])
+        dw.write_data(path=os.path.dirname(path))
+    else:
+        df = pd.DataFrame(rows)
+        df.columns = list(spec.columns)
+        df.to_csv(path)
+    return path
+
+
+def run_script(name):
+    """Entry of the per-script files (benchmark_<op>.py): the reference script's whole sweep, CSV relative to the cwd."""
+    import gnnops
+
+    if not torch.cuda.is_available():
+        raise Exception("Benchmarking only supported for CUDA")   # the reference's guard (benchmark_scatter_add.py:52-54)
+    gnnops.install()
+    print("wrote", run_sweep(name, os.getcwd()))
+
+
+# ================================================================================================================
+# point mode: one table at the reference's largest / smallest published shapes, with algorithmic GB/s and A100 numbers
+# ================================================================================================================
 def _rand(shape, dtype=H):
     return torch.rand(shape, device=DEV, dtype=torch.float32).to(dtype)
 
@@ -84,7 +577,6 @@ def _sq(L, rf=1, dtype=H):
     return src, idx
 
 
-# (name, reference max L, reference min L, A100 ms at max L by case, builder(L) -> list of (case, stmt, globals, alg_bytes))
 def cases_scatter(name, fn, has_arg=False):
     def build(L):
         out = []
@@ -175,24 +667,36 @@ def build_transpose(L):
 
 
 def build_fused_select(L):
+    """The literal body three ways: scripted (rewritten by gnnops/jit.py -> the single-pass kernel), eager (our index_select,
+    then torch's sum over the materialised [E, D]), and the fused kernel under its own name (fp32 result)."""
+    import gnnops
+
     out = []
     inp = _rand((L, L))
     index = torch.randint(0, L, (L,), device=DEV)
     for d in (0, 1):
-        g = {"input": inp, "index": index, "op_fused_index_select_reduce": op_fused_index_select_reduce,
-             "op_unfused_index_select_reduce": op_unfused_index_select_reduce}
-        out.append((f"fused dim{d}", f"op_fused_index_select_reduce(input, {d}, index)", g, L * L * 2 + L * 8))
-        out.append((f"unfused dim{d}", f"op_unfused_index_select_reduce(input, {d}, index)", g, 3 * L * L * 2 + L * 8))
+        g = {"input": inp, "index": index, "fused_gelu": scripted(gelu_select), "gelu": gelu_select,
+             "index_select_sum": gnnops.index_select_sum}
+        out.append((f"fused dim{d}", f"fused_gelu(input, {d}, index)", g, L * L * 2 + L * 8))
+        out.append((f"unfused dim{d}", f"gelu(input, {d}, index)", g, 3 * L * L * 2 + L * 8))
+        out.append((f"by name dim{d}", f"index_select_sum(input, {d}, index)", g, L * L * 2 + L * 8))
     return out
 
 
 def build_fused_add(L):
+    import gnnops
+
     inp = _rand((L, L))
     other = inp.clone()
     index = torch.randint(0, L, (L,), device=DEV)
-    return [(f"dim{d}", f"op_fused_index_add_reduce(input, {d}, index, other)",
-             {"input": inp, "index": index, "other": other, "op_fused_index_add_reduce": op_fused_index_add_reduce},
-             2 * L * L * 2 + L * 8) for d in (0, 1)]
+    out = []
+    for d in (0, 1):
+        g = {"input": inp, "index": index, "other": other, "fused_gelu": scripted(gelu_add), "gelu": gelu_add,
+             "index_add_select_sum": gnnops.index_add_select_sum}
+        out.append((f"fused dim{d}", f"fused_gelu(input, {d}, index, other)", g, 2 * L * L * 2 + L * 8))
+        out.append((f"unfused dim{d}", f"gelu(input, {d}, index, other)", g, 7 * L * L * 2 + L * 8))
+        out.append((f"by name dim{d}", f"index_add_select_sum(input, {d}, index, other)", g, 2 * L * L * 2 + L * 8))
+    return out
 
 
 def build_addmm(L):
@@ -229,7 +733,7 @@ OPS = {
     "sparse_coalesce": (3000, 500, build_coalesce, {}),
     "sparse_transpose": (7071, 2000, build_transpose, {"dense fp16": 0.709}),
     "fused_index_select_reduce": (14142, 2738, build_fused_select, {"unfused dim0": 2.920, "fused dim0": 2.921}),
-    "fused_index_add_reduce": (6708, 223, build_fused_add, {"dim0": 8.814, "dim1": 24.70}),
+    "fused_index_add_reduce": (6708, 223, build_fused_add, {"fused dim0": 8.814, "unfused dim0": 8.807, "fused dim1": 24.70, "unfused dim1": 24.64}),
     "native_addmm": (8164, 1581, build_addmm, {"fp16": 7.230}),
     "native_matmul": (8164, 1581, build_matmul, {"fp16": 8.796}),
 }
@@ -238,14 +742,26 @@ OPS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ops", default="all")
+    ap.add_argument("--sweep", default="point", choices=["point", "ref"])
     ap.add_argument("--point", default="ref_max", choices=["ref_max", "ref_min"])
-    ap.add_argument("--runs", type=int, default=20)
-    ap.add_argument("--csv", default=None)
+    ap.add_argument("--runs", type=int, default=None, help="calls per measurement (point mode: 20; ref mode: the script's own)")
+    ap.add_argument("--csv", default=None, help="point mode: write the table here")
+    ap.add_argument("--out", default=".", help="ref mode: directory the reference-named CSVs are written under")
+    ap.add_argument("--limit", type=int, default=None, help="ref mode: keep this many evenly spaced points of each sweep")
+    ap.add_argument("--num", type=int, default=None, help="ref mode: number of lengths in the linspace sweeps")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise Exception("Benchmarking only supported for CUDA")  # the reference's guard (benchmark_scatter_add.py:52-54)
+    import gnnops
+    from graph_benchmark.benchmark.util import setup_seed
+
     setup_seed(42)
     gnnops.install()
+    if args.sweep == "ref":
+        names = list(SPECS) if args.ops == "all" else args.ops.split(",")
+        for name in names:
+            print("wrote", run_sweep(name, args.out, num=args.num, limit=args.limit, runs=args.runs), flush=True)
+        return
     names = list(OPS) if args.ops == "all" else args.ops.split(",")
     rows = []
     for name in names:
@@ -253,7 +769,7 @@ def main():
         L = Lmax if args.point == "ref_max" else Lmin
         torch.cuda.empty_cache()
         for case, stmt, g, alg in build(L):
-            t = benchmark.Timer(stmt=stmt, globals=g).timeit(args.runs)
+            t = benchmark.Timer(stmt=stmt, globals=g).timeit(args.runs or 20)
             ms = t.median * 1e3
             ref = a100.get(case) if args.point == "ref_max" else None
             rows.append([name, case, f"({L}, {L})", f"{ms:.4f}", f"{alg / ms / 1e6:.1f}", "" if ref is None else ref,

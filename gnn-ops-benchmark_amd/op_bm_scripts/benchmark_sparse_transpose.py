@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""`python op_bm_scripts/benchmark_sparse_transpose.py` — the reference script of the same name (its sweep, its timer protocol, its CSV
+`mem_prof_data/sparse_transpose.csv`), run by the spec of benchmark_ops.py on the gfx950 kernels."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import benchmark_ops
+
+if __name__ == "__main__":
+    benchmark_ops.run_script("sparse_transpose")

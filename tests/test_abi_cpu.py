@@ -169,3 +169,50 @@ def test_raw_ops_never_drop_a_gradient_silently():
 
     assert gnnops.scatter is autograd.scatter and gnnops.index_select is autograd.index_select
     assert gnnops.addmm is autograd.addmm
+
+
+def test_runner_writes_the_reference_csv_schemas():
+    """a18: every one of the reference's 17 scripts has a spec whose CSV path and header row equal what the reference's
+    script (or its DataWriter) writes — fixture tests/golden/csv_headers.json, generated from the reference by
+    tests/golden/make_csv_headers.py — and a same-named entry script."""
+    import importlib.util
+    import json
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    scripts = os.path.join(root, "gnn-ops-benchmark_amd", "op_bm_scripts")
+    spec = importlib.util.spec_from_file_location("benchmark_ops", os.path.join(scripts, "benchmark_ops.py"))
+    bo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bo)
+    fixture = json.load(open(os.path.join(here, "golden", "csv_headers.json")))
+    assert sorted(bo.SPECS) == sorted(fixture) and len(fixture) == 17
+    for op, info in fixture.items():
+        path, cols = bo.spec_header(op)
+        assert path == info["csv"], op
+        assert cols == info["columns"], op
+        assert bo.SPECS[op].script == info["script"], op
+        assert os.path.exists(os.path.join(scripts, info["script"])), op
+    # sweeps: the loops of the reference scripts (counts from their range literals)
+    counts = {op: sum(1 for _ in bo.SPECS[op].sweep(bo.SPECS[op].num)) for op in bo.SPECS}
+    assert counts["scatter_add"] == 4 * 100 * 2 and counts["scatter_min"] == 800      # RF x lengths x dim
+    assert counts["native_index_select"] == 10 * 2 * 4 and counts["fused_index_select_reduce"] == 100 * 2 * 4
+    assert counts["native_index_add_"] == 10 and counts["native_gather"] == 20 and counts["fused_index_add_reduce"] == 200
+    assert counts["native_sort"] == 4 * (1 + 2 + 3) * 2 and counts["scatter_multiply"] == 4 * 4 * 2
+    assert counts["sparse_coalesce"] == 3 * 2 * 4 and counts["sparse_spmm"] == 10 and counts["sparse_transpose"] == 10
+    assert counts["native_addmm"] == 100 and counts["native_matmul"] == 100
+    first = next(iter(bo.SPECS["scatter_add"].sweep(100)))
+    assert first["src_dims"] == (223, 223)                      # int(sqrt(50_000)): the reference's first length
+    assert bo.lengths(7_500_000, 200_000_000, 10)[-1] == 14142   # benchmark_native_index_select.py:38-39
+    # the DataWriter row format the sort spec relies on
+    from graph_benchmark.benchmark.DataWriter import DataWriter
+    import tempfile
+
+    dw = DataWriter(op_name="native_sort", param_names=fixture["native_sort"]["columns"][0])
+    dw.add_entry(params_lst=["1", "0", "True"], tshape=(3,), sparsity=0, bm_val=1.5)
+    with tempfile.TemporaryDirectory() as tmp:
+        dw.write_data(path=tmp)
+        lines = open(os.path.join(tmp, "native_sort.csv")).read().splitlines()
+    import csv
+
+    assert next(csv.reader([lines[0]]))[1:] == fixture["native_sort"]["columns"]
+    assert lines[1] == fixture["native_sort"]["datawriter_row"]
