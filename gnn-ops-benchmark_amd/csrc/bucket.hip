@@ -82,16 +82,7 @@ __device__ inline uint32_t sort_chunk(const uint32_t* __restrict__ keys, const u
                 vv[r] = vals[cbeg + i];
             }
             const uint32_t d = dg[r];
-            const uint64_t vb = __ballot(valid);
-            uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
-                const uint64_t bal = __ballot(xb != 0u);
-                m_lo &= ~((uint32_t)bal ^ xb);
-                m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
-            }
-            const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;   // valid lanes with my key
+            const uint64_t m = match_digit8(d, __ballot(valid));   // valid lanes with my key
             const uint32_t below = __popcll(m & lanes_below);
             if (valid && below == 0) {
                 rk[r] = atomicAdd(&whist[d], (uint32_t)__popcll(m));  // rank of the group inside this wave
@@ -152,16 +143,7 @@ __device__ __noinline__ int32_t hub_prepare(const uint32_t* __restrict__ keys, c
         const int32_t i = i0 + (tid & 63);
         const bool valid = i < bend;
         const uint32_t d = valid ? (keys[i] & (BROWS - 1)) : 0u;
-        const uint64_t vb = __ballot(valid);
-        uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
-            const uint64_t bal = __ballot(xb != 0u);
-            m_lo &= ~((uint32_t)bal ^ xb);
-            m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
-        }
-        const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
+        const uint64_t m = match_digit8(d, __ballot(valid));
         const uint64_t below = (tid & 63) ? (m & (~0ull >> (64 - (tid & 63)))) : 0ull;
         if (valid && below == 0) atomicAdd(&s_deg[d], (uint32_t)__popcll(m));
     }

@@ -141,6 +141,33 @@ template <> struct Red<GNNOPS_MAX> {
 
 __device__ static inline int lane_id() { return threadIdx.x & 63; }
 
+// ---- launch order -> work item, XCD-aware ----
+// Consecutive block ids go round-robin to the 8 XCDs (each with its own L2; MI355X_MICROARCH.md "Workgroup dispatch"), so
+// XCD x is given a CONTIGUOUS run of items: neighbouring items — which touch neighbouring bytes of the same lines (column
+// strips of one row, the digit runs two adjacent radix tiles write, their slots of one tile-histogram line) — then meet in
+// ONE L2, where partial lines merge before they reach memory, instead of in eight. Speed only: any placement is correct.
+__device__ inline int64_t xcd_contiguous(int64_t bid, int64_t total) {
+    const int64_t q = total / 8, r = total % 8, x = bid % 8;
+    return x * q + (x < r ? x : r) + bid / 8;
+}
+
+// ---- peers of this lane: the lanes of `valid` whose 8-bit digit equals mine (the match step of every stable ranking) ----
+// Eight ballots; per bit one sign-extension, one compare and ONE three-input boolean per 32-lane half
+// (v_bitop3_b32, table 0x90 = a & ~(b ^ c)): 4 vector instructions per bit. The asm barrier keeps the compiler from
+// re-deriving the ballot operand from `d` (it would add a shift per bit).
+__device__ inline uint64_t match_digit8(uint32_t d, uint64_t valid) {
+    uint32_t m_lo = (uint32_t)valid, m_hi = (uint32_t)(valid >> 32);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        uint32_t x = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // all ones if bit b of the digit is set
+        asm("" : "+v"(x));
+        const uint64_t bal = __ballot(x != 0u);
+        m_lo = __builtin_amdgcn_bitop3_b32(m_lo, (uint32_t)bal, x, 0x90);
+        m_hi = __builtin_amdgcn_bitop3_b32(m_hi, (uint32_t)(bal >> 32), x, 0x90);
+    }
+    return ((uint64_t)m_hi << 32) | m_lo;
+}
+
 // ---- block-level exclusive scan of one u32 per thread (NW waves); s_tmp: NW words of LDS ----
 __device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
     const int lane = threadIdx.x & 63;

@@ -156,14 +156,6 @@ __global__ void zero_empty_kernel(T* __restrict__ out, const int64_t* __restrict
 constexpr int LDS_THREADS = 1024;
 constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
 
-// Launch order -> work item: consecutive block ids go round-robin to the 8 XCDs (each with its own L2), so XCD x is given
-// a CONTIGUOUS run of items: neighbouring column strips — which share the 64/128-B lines of every src / index row — are
-// then streamed at the same time through the same L2 instead of being fetched once per XCD.
-__device__ inline int64_t xcd_contiguous(int64_t bid, int64_t total) {
-    const int64_t q = total / 8, r = total % 8, x = bid % 8;
-    return x * q + (x < r ? x : r) + bid / 8;
-}
-
 template <typename T, int R>
 __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __restrict__ src,
                                                                   const int64_t* __restrict__ index,

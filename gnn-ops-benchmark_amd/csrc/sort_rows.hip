@@ -72,16 +72,7 @@ __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restr
                 const int i = wave_base + r * 64 + lane;
                 const bool valid = i < E;
                 const uint32_t d = (key[r] >> shift) & 255u;
-                const uint64_t vb = __ballot(valid);
-                uint32_t m_lo = (uint32_t)vb, m_hi = (uint32_t)(vb >> 32);
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const uint32_t xb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
-                    const uint64_t bal = __ballot(xb != 0u);
-                    m_lo &= ~((uint32_t)bal ^ xb);
-                    m_hi &= ~((uint32_t)(bal >> 32) ^ xb);
-                }
-                const uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
+                const uint64_t m = match_digit8(d, __ballot(valid));
                 const uint32_t below = __popcll(m & lanes_below);
                 uint32_t lo;  // 16 bits: the LDS add's return (leader) or below | leader_lane << 8 (others)
                 if (valid && below == 0) {

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgnnops.so")
+# GNNOPS_LIB_PATH: another build of the same ABI (A/B timing of two builds on one box: tools/time_partition.py)
+LIB_PATH = os.environ.get("GNNOPS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libgnnops.so")
 
 F32, F16, BF16 = 0, 1, 2
 SUM, MEAN, MIN, MAX, MUL = 0, 1, 2, 3, 4
