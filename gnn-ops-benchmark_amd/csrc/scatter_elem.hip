@@ -156,9 +156,9 @@ __global__ void zero_empty_kernel(T* __restrict__ out, const int64_t* __restrict
 constexpr int LDS_THREADS = 1024;
 constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
 
-template <typename T, int R>
+template <typename T, int R, typename I>
 __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __restrict__ src,
-                                                                  const int64_t* __restrict__ index,
+                                                                  const I* __restrict__ index,
                                                                   T* __restrict__ out, int64_t* __restrict__ arg_out,
                                                                   int64_t B, int64_t E, int64_t K, int64_t N, int TC,
                                                                   int strips, int64_t rows, int nchunks,
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
     __syncthreads();
 
     const T* sp = src + (b * E) * K + k0 + kk;
-    const int64_t* ip = index + (b * E) * K + k0 + kk;
+    const I* ip = index + (b * E) * K + k0 + kk;
     if (col_ok) {
         for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
             int64_t nl[UNR];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
             for (int u = 0; u < UNR; ++u) {
                 const int64_t e = e0 + (int64_t)u * rpi;
                 const int64_t ec = e < E ? e : E - 1;
-                nl[u] = ip[ec * K];
+                nl[u] = (int64_t)ip[ec * K];
                 v[u] = Elem<T>::load(sp + ec * K);
             }
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
                 for (int u = 0; u < UNR; ++u) {
                     const int64_t e = e0 + (int64_t)u * rpi;
                     const int64_t ec = e < E ? e : E - 1;
-                    nl[u] = ip[ec * K];
+                    nl[u] = (int64_t)ip[ec * K];
                     v[u] = Elem<T>::load(sp + ec * K);
                 }
 #pragma unroll
@@ -314,9 +314,9 @@ __device__ inline CellT order_image(const T* p, float v) {
     else return (CellT)b16_order(*reinterpret_cast<const uint16_t*>(p));
 }
 
-template <typename T, int R, typename CellT>
+template <typename T, int R, typename CellT, typename I>
 __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T* __restrict__ src,
-                                                                         const int64_t* __restrict__ index,
+                                                                         const I* __restrict__ index,
                                                                          T* __restrict__ out, int64_t* __restrict__ arg_out,
                                                                          int64_t B, int64_t E, int64_t K, int64_t N, int TC,
                                                                          int strips, int64_t rows, int nchunks,
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
     __syncthreads();
 
     const T* sp = src + (b * E) * K + k0 + kk;
-    const int64_t* ip = index + (b * E) * K + k0 + kk;
+    const I* ip = index + (b * E) * K + k0 + kk;
     if (col_ok) {
         for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
             int64_t nl[UNR];
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
             for (int u = 0; u < UNR; ++u) {
                 const int64_t e = e0 + (int64_t)u * rpi;
                 const int64_t ec = e < E ? e : E - 1;
-                nl[u] = ip[ec * K];
+                nl[u] = (int64_t)ip[ec * K];
                 vt[u] = sp[ec * K];
             }
 #pragma unroll
@@ -471,12 +471,12 @@ inline LdsGeom lds_geometry(int64_t N, int64_t K, int reduce, bool small_cell = 
     return LdsGeom{(int)tc, rows, (int)nchunks};
 }
 
-template <typename T, int R>
-int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int64_t B, int64_t E, int64_t K, int64_t N,
+template <typename T, int R, typename I>
+int launch_lds(const T* src, const I* index, T* out, int64_t* arg_out, int64_t B, int64_t E, int64_t K, int64_t N,
                LdsGeom g, int init_from_out, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_kernel<T, R>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_kernel<T, R, I>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
             return gnnops_check_launch("scatter_lds attribute");
         configured = true;
@@ -494,14 +494,14 @@ int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int
             using CellT = decltype(cell_tag);
             static bool configured_mm = false;
             if (!configured_mm) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_minmax_kernel<T, R, CellT>),
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_minmax_kernel<T, R, CellT, I>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET) != hipSuccess)
                     return gnnops_check_launch("scatter_lds attribute");
                 configured_mm = true;
             }
             const size_t lds_mm = (size_t)g.rows * g.tc * sizeof(CellT);
             const int th = lds_mm > 80 * 1024 ? LDS_THREADS : lds_mm > 40 * 1024 ? 512 : 256;
-            hipLaunchKernelGGL((scatter_lds_minmax_kernel<T, R, CellT>), dim3((unsigned)(B * strips * g.nchunks)), dim3(th),
+            hipLaunchKernelGGL((scatter_lds_minmax_kernel<T, R, CellT, I>), dim3((unsigned)(B * strips * g.nchunks)), dim3(th),
                                lds_mm, stream, src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks,
                                init_from_out, tshift);
             return gnnops_check_launch("scatter_lds");
@@ -509,20 +509,20 @@ int launch_lds(const T* src, const int64_t* index, T* out, int64_t* arg_out, int
         if (small_cells(R, (int)sizeof(T), E)) return go(uint32_t{});
         return go((unsigned long long)0);
     }
-    hipLaunchKernelGGL((scatter_lds_kernel<T, R>), dim3((unsigned)(B * strips * g.nchunks)), dim3(threads), lds, stream,
+    hipLaunchKernelGGL((scatter_lds_kernel<T, R, I>), dim3((unsigned)(B * strips * g.nchunks)), dim3(threads), lds, stream,
                        src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks, init_from_out, tshift);
     return gnnops_check_launch("scatter_lds");
 }
 
-template <typename T>
-int dispatch_lds(int reduce, const T* src, const int64_t* index, T* out, int64_t* arg_out, int64_t B, int64_t E,
+template <typename T, typename I>
+int dispatch_lds(int reduce, const T* src, const I* index, T* out, int64_t* arg_out, int64_t B, int64_t E,
                  int64_t K, int64_t N, LdsGeom g, int init_from_out, hipStream_t stream) {
     switch (reduce) {
-        case GNNOPS_SUM: return launch_lds<T, GNNOPS_SUM>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
-        case GNNOPS_MEAN: return launch_lds<T, GNNOPS_MEAN>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
-        case GNNOPS_MUL: return launch_lds<T, GNNOPS_MUL>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
-        case GNNOPS_MIN: return launch_lds<T, GNNOPS_MIN>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
-        case GNNOPS_MAX: return launch_lds<T, GNNOPS_MAX>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_SUM: return launch_lds<T, GNNOPS_SUM, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MEAN: return launch_lds<T, GNNOPS_MEAN, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MUL: return launch_lds<T, GNNOPS_MUL, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MIN: return launch_lds<T, GNNOPS_MIN, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MAX: return launch_lds<T, GNNOPS_MAX, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
     }
     return GNNOPS_EINVAL;
 }
@@ -531,8 +531,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int grid_for(int64_t n) { return gnnops_grid_cap(gnnops_cdiv(n, 256), 256 * 16); }
 
 template <typename T>
-int run(const void* src_, const int64_t* index, void* out_, int64_t* arg_out, int64_t B, int64_t E, int64_t K,
+int run(const void* src_, const void* index_, int index_bytes, void* out_, int64_t* arg_out, int64_t B, int64_t E, int64_t K,
         int64_t N, int reduce, int init_from_out, void* workspace, hipStream_t stream) {
+    const int64_t* index = (const int64_t*)index_;   // the memory-side-atomic fallback below takes the int64 index only
     const T* src = (const T*)src_;
     T* out = (T*)out_;
     const int64_t nout = B * N * K, nsrc = B * E * K;
@@ -541,8 +542,18 @@ int run(const void* src_, const int64_t* index, void* out_, int64_t* arg_out, in
     char* w = (char*)workspace;
 
     if (const LdsGeom g = lds_geometry(N, K, reduce, small_cells(reduce, (int)sizeof(T), E), B);
-        g.tc > 0 && B * gnnops_cdiv(K, g.tc) * g.nchunks < ((int64_t)1 << 31) && E < ((int64_t)1 << 31))
-        return dispatch_lds<T>(reduce, src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        g.tc > 0 && B * gnnops_cdiv(K, g.tc) * g.nchunks < ((int64_t)1 << 31) && E < ((int64_t)1 << 31)) {
+        if (index_bytes == 4)
+            return dispatch_lds<T, int32_t>(reduce, src, (const int32_t*)index_, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        if (index_bytes == 2)
+            return dispatch_lds<T, uint16_t>(reduce, src, (const uint16_t*)index_, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        return dispatch_lds<T, int64_t>(reduce, src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+    }
+    if (index_bytes != 8) {
+        gnnops_set_error("scatter_elementwise: a narrowed index is taken by the LDS-strip form only (B=%lld N=%lld K=%lld)",
+                         (long long)B, (long long)N, (long long)K);
+        return GNNOPS_EUNSUPPORTED;
+    }
 
     if (reduce == GNNOPS_SUM || reduce == GNNOPS_MEAN || reduce == GNNOPS_MUL) {
         // fp32 accumulator: `out` itself for fp32, a scratch for 16-bit types (rounded once at the end)
@@ -614,9 +625,22 @@ extern "C" int gnnops_scatter_elementwise(const void* src, const int64_t* index,
                                           int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce,
                                           int init_from_out, void* workspace, size_t workspace_bytes,
                                           gnnops_stream_t s) {
+    return gnnops_scatter_elementwise_ix(src, index, 8, out, arg_out, B, E, K, N, dtype, reduce, init_from_out, workspace,
+                                         workspace_bytes, s);
+}
+
+// The same with the index stored in `index_bytes` bytes per element: 8 (int64, what the reference builds), 4 (int32) or 2
+// (uint16, N <= 65536) — a narrowed copy made once by gnnops_narrow_index and reused while the index tensor lives (SURVEY.md
+// 8(f) rank 2: at the reference's layout-F shapes the int64 index is 8 of every 10 bytes the op reads).
+extern "C" int gnnops_scatter_elementwise_ix(const void* src, const void* index, int index_bytes, void* out, int64_t* arg_out,
+                                             int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce,
+                                             int init_from_out, void* workspace, size_t workspace_bytes,
+                                             gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(B >= 0 && E >= 0 && K >= 0 && N >= 0, GNNOPS_EINVAL, "scatter_elementwise: negative size");
     GNNOPS_REQUIRE(reduce >= GNNOPS_SUM && reduce <= GNNOPS_MUL, GNNOPS_EINVAL, "scatter_elementwise: reduce %d", reduce);
+    GNNOPS_REQUIRE(index_bytes == 8 || index_bytes == 4 || (index_bytes == 2 && N <= 65536), GNNOPS_EINVAL,
+                   "scatter_elementwise: index_bytes %d (N=%lld)", index_bytes, (long long)N);
     GNNOPS_REQUIRE(!(reduce == GNNOPS_MEAN && init_from_out), GNNOPS_EINVAL,
                    "scatter_elementwise: mean cannot start from out");
     GNNOPS_REQUIRE((reduce != GNNOPS_MIN && reduce != GNNOPS_MAX) || arg_out != nullptr || init_from_out,
@@ -627,10 +651,54 @@ extern "C" int gnnops_scatter_elementwise(const void* src, const int64_t* index,
     GNNOPS_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), GNNOPS_EWORKSPACE,
                    "scatter_elementwise: workspace %zu < %zu", workspace_bytes, need);
     switch (dtype) {
-        case GNNOPS_F32: return run<float>(src, index, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
-        case GNNOPS_F16: return run<__half>(src, index, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
-        case GNNOPS_BF16: return run<__hip_bfloat16>(src, index, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
+        case GNNOPS_F32: return run<float>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
+        case GNNOPS_F16: return run<__half>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
+        case GNNOPS_BF16: return run<__hip_bfloat16>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
     }
     gnnops_set_error("scatter_elementwise: unknown dtype %d", dtype);
     return GNNOPS_EINVAL;
+}
+
+namespace {
+// int64 -> int32 / uint16, streaming: 16-B loads (two entries), 8-B / 4-B stores; eight loads in flight per lane
+template <typename O>
+__global__ __launch_bounds__(256) void narrow_index_kernel(const int64_t* __restrict__ in, O* __restrict__ out, int64_t n) {
+    typedef long long ll2_t __attribute__((ext_vector_type(2)));
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    const bool vec = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % (2 * sizeof(O)) == 0);
+    const int64_t n2 = vec ? n / 2 : 0;
+    const ll2_t* p = reinterpret_cast<const ll2_t*>(in);
+    int64_t i = gtid;
+    for (; i + 7 * stride < n2; i += 8 * stride) {
+        ll2_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            O* q = out + 2 * (i + u * stride);
+            q[0] = (O)v[u].x;
+            q[1] = (O)v[u].y;
+        }
+    }
+    for (; i < n2; i += stride) {
+        const ll2_t a = __builtin_nontemporal_load(p + i);
+        out[2 * i] = (O)a.x;
+        out[2 * i + 1] = (O)a.y;
+    }
+    for (int64_t j = 2 * n2 + gtid; j < n; j += stride) out[j] = (O)in[j];
+}
+}  // namespace
+
+// out[i] = (int32 / uint16) index[i]: the narrowed copy gnnops_scatter_elementwise_ix / gnnops_gather_ix read. Values must
+// fit (the caller knows the bound: every entry lies in [0, N)).
+extern "C" int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_bytes, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(n >= 0 && (out_bytes == 4 || out_bytes == 2), GNNOPS_EINVAL, "narrow_index: bad argument");
+    if (n == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(index && out, GNNOPS_EINVAL, "narrow_index: null pointer");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(n, 256 * 16), 256 * 8);
+    if (out_bytes == 4)
+        hipLaunchKernelGGL(narrow_index_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, index, (int32_t*)out, n);
+    else
+        hipLaunchKernelGGL(narrow_index_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, index, (uint16_t*)out, n);
+    return gnnops_check_launch("narrow_index");
 }

@@ -150,10 +150,12 @@ def set_plan_cache(enabled):
     _plan_cache_enabled = bool(enabled)
     if not enabled:
         _plan_cache.clear()
+        _narrow_cache.clear()
 
 
 def clear_plan_cache():
     _plan_cache.clear()
+    _narrow_cache.clear()
 
 
 def _version_of(t):
@@ -193,6 +195,43 @@ def get_plan(index, N, owner=None, tag=0):
     return plan
 
 
+# ---- narrowed copies of full-shape (layout F) indices -------------------------------------------------------------
+# At the reference's own shapes (benchmark_scatter_add.py:67-84: src fp16 (L, L), index int64 (L, L)) the index is 8 of every
+# 10 bytes the op reads. An index tensor that is passed a second time (unchanged: same object, same version counter) gets a
+# 2-byte (N <= 65536) or 4-byte copy, kept while the tensor lives; the element kernels then stream that. The first call
+# pays nothing extra, the second the narrowing pass (12 B per entry once), every later one reads 2-4 B instead of 8.
+_narrow_cache = {}        # id(index) -> [weakref, version, bound, None | (narrow tensor, bytes) | "unsupported"]
+_NARROW_CACHE_MAX = 8
+
+
+def _narrowed(index, full, bound):
+    """(tensor, bytes per entry) to hand to the element kernels for the full-shape index `full` of the user's `index`."""
+    if not _plan_cache_enabled or bound >= 2 ** 31 or _version_of(index) is None:
+        return full, 8
+    key = id(index)
+    hit = _narrow_cache.get(key)
+    if hit is None or hit[0]() is not index or hit[1] != index._version or hit[2] != bound:
+        if len(_narrow_cache) >= _NARROW_CACHE_MAX:
+            _narrow_cache.pop(next(iter(_narrow_cache)))
+        _narrow_cache[key] = [weakref.ref(index, lambda _r, key=key: _narrow_cache.pop(key, None)), index._version, bound, None]
+        return full, 8                                  # first sighting: nothing to amortise yet
+    if hit[3] == "unsupported":
+        return full, 8
+    if hit[3] is None:
+        nbytes = 2 if bound <= 65536 else 4
+        narrow = torch.empty(full.shape, dtype=torch.int16 if nbytes == 2 else torch.int32, device=full.device)
+        with torch.cuda.device(full.device):
+            check(_lib.load().gnnops_narrow_index(full.data_ptr(), narrow.data_ptr(), full.numel(), nbytes, _stream()), "narrow_index")
+        hit[3] = (narrow, nbytes)
+    return hit[3]
+
+
+def _narrow_unsupported(index):
+    hit = _narrow_cache.get(id(index))
+    if hit is not None:
+        hit[3] = "unsupported"
+
+
 def index_max(index):
     """int(index.max()) computed by our reduction kernel; -1 for an empty index. Synchronises (like the
     reference's implicit ``index.max()`` in torch_scatter when dim_size is None)."""
@@ -209,6 +248,9 @@ def index_max(index):
 # --------------------------------------------------------------------------------------------------
 # scatter family
 # --------------------------------------------------------------------------------------------------
+_LDS_STRIP_BYTES = 160 * 1024 - 512   # csrc/scatter_elem.hip LDS_BUDGET: what one workgroup's strip of destinations may take
+
+
 def _row_index_of(index, src, dim):
     """Return a contiguous 1-D index if `index` is (a broadcast of) a row index along `dim`, else None."""
     if index.dim() == 1 and index.numel() == src.size(dim):
@@ -270,6 +312,22 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
             N = index.N
         else:
             N = index_max(index if row_index is None else row_index) + 1 if index.numel() else 0
+        if row_index is None and B == 1 and K > 1 and E < 2 ** 31:
+            cell = 4 if (reduce in ("sum", "add", "mul") or (reduce in ("min", "max") and src.element_size() == 2 and E < 65535)) else 8
+            if N * cell > _LDS_STRIP_BYTES:
+                # layout F along dim 0 of a matrix whose destinations do not fit an LDS strip (the reference's (38000, 38000)
+                # shapes, data/scatter_max.csv:32-33): the element kernel would re-scan every column strip once per chunk of
+                # destinations, through 16-B-wide column pieces. Along the LAST dim the same problem streams whole rows, so:
+                # tile-transpose src and index, reduce along dim 1, transpose the results back (streaming copies).
+                from .sparse import transpose_contiguous
+
+                shape = list(src.shape)
+                shape[dim] = N
+                full = _broadcast_index(index, src, dim).contiguous().view(E, K)      # B == 1: [E, K] around `dim`
+                res = scatter(transpose_contiguous(src.view(E, K)), transpose_contiguous(full), 1, None, N, reduce)
+                if isinstance(res, tuple):
+                    return transpose_contiguous(res[0]).view(shape), transpose_contiguous(res[1]).view(shape)
+                return transpose_contiguous(res).view(shape)
         shape = list(src.shape)
         shape[dim] = N
         out = torch.empty(shape, dtype=src.dtype, device=src.device)
@@ -279,7 +337,9 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
     if row_index is not None and not is_plan and (E >= 2 ** 31 or N >= 2 ** 31):
         row_index = None  # beyond the plan's int32 range: the element-wise kernel takes int64 sizes
     with torch.cuda.device(src.device):
-        if row_index is not None and not is_plan and B == 1 and not _plan_cache_enabled and E > 0 and (
+        vec = 16 // src.element_size()
+        rows_ok = K % vec == 0 and src.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0     # rows of whole 16-B lanes
+        if row_index is not None and not is_plan and B == 1 and not _plan_cache_enabled and E > 0 and rows_ok and N > 256 and (
                 src.dtype == torch.float32 or want_arg):
             # nothing will reuse a plan: fold the end of its construction into the reduction (bucket.hip). 16-bit
             # sums / means / products stay on the plan path (one rounding of the fp32 accumulator, whatever the skew).
@@ -307,9 +367,15 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
             full = _broadcast_index(index, src, dim).contiguous()
             ws_bytes = L.gnnops_scatter_elementwise_workspace_bytes(B, N, K, dt, rcode)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=src.device)
-            rc = L.gnnops_scatter_elementwise(src.data_ptr(), full.data_ptr(), out.data_ptr(),
-                                              arg.data_ptr() if want_arg else None, B, E, K, N, dt, rcode, init,
-                                              ws.data_ptr(), ws_bytes, _stream())
+            ix, ix_bytes = _narrowed(index, full, N)
+            rc = L.gnnops_scatter_elementwise_ix(src.data_ptr(), ix.data_ptr(), ix_bytes, out.data_ptr(),
+                                                 arg.data_ptr() if want_arg else None, B, E, K, N, dt, rcode, init,
+                                                 ws.data_ptr(), ws_bytes, _stream())
+            if rc == _lib.EUNSUPPORTED and ix_bytes != 8:   # not the LDS-strip form: the int64 index, and remember it
+                _narrow_unsupported(index)
+                rc = L.gnnops_scatter_elementwise_ix(src.data_ptr(), full.data_ptr(), 8, out.data_ptr(),
+                                                     arg.data_ptr() if want_arg else None, B, E, K, N, dt, rcode, init,
+                                                     ws.data_ptr(), ws_bytes, _stream())
             check(rc, "scatter_elementwise")
     return (out, arg) if want_arg else out
 

@@ -167,6 +167,15 @@ int gnnops_scatter_elementwise(const void* src, const int64_t* index, void* out,
                                int64_t B, int64_t E, int64_t K, int64_t N,
                                int dtype, int reduce, int init_from_out,
                                void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+/* The same with the index stored in `index_bytes` bytes per element: 8 (int64, what the reference builds), 4 (int32) or 2
+ * (uint16, N <= 65536) — SURVEY.md 8(f) rank 2: at the reference's layout-F shapes (benchmark_scatter_add.py:78-84) the
+ * int64 index is 8 of every 10 bytes the op reads; a narrowed copy (gnnops_narrow_index) is made once per index tensor and
+ * reused. A narrowed index is taken by the LDS-strip form only: GNNOPS_EUNSUPPORTED otherwise (pass the int64 index). */
+int gnnops_scatter_elementwise_ix(const void* src, const void* index, int index_bytes, void* out, int64_t* arg_out,
+                                  int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
+                                  void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+/* out[i] = (int32 / uint16) index[i], i < n; out_bytes 4 or 2. Every entry must fit. */
+int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch.index_select (benchmark_native_index_select.py:12-15; also the first half of

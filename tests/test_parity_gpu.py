@@ -492,3 +492,74 @@ def test_csr_cache_hits_for_the_same_coo_tensor(gnnops):
             sparse._permute = real
     finally:
         gnnops.set_plan_cache(False)
+
+
+@pytest.mark.parametrize("dname,reduce", [("f32", "max"), ("f32", "min"), ("f32", "mean"), ("f32", "sum"), ("f16", "sum"), ("f32", "mul")])
+def test_layout_f_dim0_more_destinations_than_an_lds_strip(gnnops, oracle, reduce, dname):
+    """Full-shape index along dim 0 with N too large for an LDS strip of destinations (the reference's (38000, 38000) shapes,
+    data/scatter_max.csv:32-33): routed through tile transposes + the last-dim kernel. Values and arg bit-exact for min / max,
+    sums / means / products within the layout-F tolerance; also a 3-D src reduced along dim 0."""
+    g = torch.Generator().manual_seed(12)
+    E, K = 300, 24
+    N = 45_000 if reduce in ("sum", "mul") else 21_000          # > 159.5 KiB / (4 or 8 B per destination)
+    src = (torch.rand(E, K, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    idx = torch.randint(0, N, (E, K), generator=g)
+    idx[:40] = idx[40:80]                                        # ties for min / max, repeated destinations for sums
+    got = gnnops.scatter(src.cuda(), idx.cuda(), 0, dim_size=N, reduce=reduce)
+    exp = oracle.scatter(to_np(src), idx.numpy(), dim=0, dim_size=N, reduce=reduce, dtype=dname)
+    if reduce in ("min", "max"):
+        assert_bits_equal(to_np(got[0]), exp[0], reduce)
+        assert np.array_equal(got[1].cpu().numpy(), exp[1])
+    else:
+        _close(to_np(got), exp, dname, 4, reduce)
+    src3 = src.view(E, 4, 6)
+    got3 = gnnops.scatter(src3.cuda(), idx.view(E, 4, 6).cuda(), 0, dim_size=N, reduce=reduce)
+    g3 = got3[0] if isinstance(got3, tuple) else got3
+    e3 = exp[0] if isinstance(exp, tuple) else exp
+    assert g3.shape == (N, 4, 6)
+    _close(to_np(g3).reshape(N, K), e3, dname, 4, reduce + " 3-D")
+
+
+@pytest.mark.parametrize("N,dname", [(700, "f16"), (700, "f32"), (70_000, "f32"), (65536, "bf16"), (65537, "f16")])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max", "mul"])
+def test_layout_f_narrowed_index_copies(gnnops, oracle, reduce, N, dname):
+    """a full-shape index passed again (same tensor, unchanged) is streamed from a 2-byte (N <= 65536)
+    or 4-byte copy. First call int64, second call narrows, third reuses; an in-place write to the index invalidates the
+    copy. Same results as the int64 index every time (min / max / arg bit-exact, sums within the layout-F tolerance)."""
+    from gnnops import ops
+
+    g = torch.Generator().manual_seed(N)
+    L, K = 160, 48
+    src = (torch.rand(L, K, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    idx = torch.randint(0, N, (L, K), generator=g)
+    idx[0, 0] = N - 1
+    d_src, d_idx = src.cuda(), idx.cuda()
+    gnnops.set_plan_cache(True)
+    try:
+        for dim in (0, 1):
+            n_out = N
+            exp = oracle.scatter(to_np(src), idx.numpy(), dim=dim, dim_size=n_out, reduce=reduce, dtype=dname)
+            for call in range(3):
+                got = gnnops.scatter(d_src, d_idx, dim, dim_size=n_out, reduce=reduce)
+                if reduce in ("min", "max"):
+                    assert_bits_equal(to_np(got[0]), exp[0], f"{reduce} call {call}")
+                    assert np.array_equal(got[1].cpu().numpy(), exp[1])
+                else:
+                    _close(to_np(got), exp, dname, 8, f"{reduce} call {call}")
+            hit = ops._narrow_cache.get(id(d_idx))
+            cell = 4 if reduce in ("sum", "mul") or (reduce in ("min", "max") and dname != "f32") else 8
+            if dim == 0 and N * cell > ops._LDS_STRIP_BYTES:
+                continue          # routed through transposes (fresh tensors every call): nothing to key a copy on
+            assert hit is not None and hit[3] not in (None,), "the second call must have narrowed (or recorded why not)"
+            if hit[3] != "unsupported":
+                assert hit[3][1] == (2 if N <= 65536 else 4)
+        d_idx[1, 1] = 0                                   # in-place write: version bump -> the copy is stale and dropped
+        idx[1, 1] = 0
+        exp = oracle.scatter(to_np(src), idx.numpy(), dim=0, dim_size=N, reduce=reduce, dtype=dname)
+        for call in range(3):
+            got = gnnops.scatter(d_src, d_idx, 0, dim_size=N, reduce=reduce)
+            g0 = got[0] if isinstance(got, tuple) else got
+            e0 = exp[0] if isinstance(exp, tuple) else exp
+            _close(to_np(g0), e0, dname, 8, f"after write, call {call}")
+    finally:
+        gnnops.set_plan_cache(False)
