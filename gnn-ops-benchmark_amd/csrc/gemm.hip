@@ -853,6 +853,249 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
     }
 }
 
+// ---- fp32, big tiles: 256 x 256 block tile, eight waves of 128 x 64, operands staged by LDS-DMA --------------------
+// The 128 x 128 kernel above reads 16 KiB of operands per 0.5 MFLOP; at the reference's (48000)^3 (data/native_addmm.csv:2)
+// that is ~4.7 TB/s of L2 -> LDS traffic and 32 fragment reads per 64 MFMAs, and the chip holds a lower clock under it than
+// under a kernel that moves half of that. Here: BK = 16, stage = A [256][16] (64-B rows: the a4_off image of the 16-bit
+// kernels, a lane's fragment = ONE ds_read_b128 = its row's k = 4q .. 4q+3) + B [16][256] with a row pitch of 1040 B (the
+// four k-rows a 32-lane half reads fall on disjoint banks). The four MFMA steps of a K-step take k = 4q + j from lane
+// group q (any order of k is a valid order of the sum: the SAME permutation on both operands), so A needs no scalar
+// reads at all. Three stages; the DMA of tile t+2 is issued right after the fragments of tile t are in registers, so at
+// the top of a K-step the only outstanding DMA is one whole K-step (>= 4096 MFMA cycles) old: a plain vmcnt(0) there
+// costs nothing and no hand-counted wait is needed. Tiles are handed out XCD-contiguously in 8-wide column strips:
+// the 32 workgroups of an XCD work on 4 x 8 neighbouring tiles (4 A panels + 8 B panels through one L2).
+// Needs K % 16 == 0, N % 4 == 0 and 16-B aligned operands (the host falls back to the 128 x 128 kernel otherwise);
+// any M and N (filler rows / columns, guarded epilogue).
+constexpr int F2_BK = 16, F2_NST = 3;
+constexpr int F2_A_BYTES = 256 * F2_BK * 4;   // 16 KiB
+constexpr int F2_BROW = 1040;                  // B row pitch in bytes: 256 floats + 16 B
+constexpr int F2_B_BYTES = F2_BK * F2_BROW;    // 16640
+constexpr int F2_STAGE = F2_A_BYTES + F2_B_BYTES;
+constexpr int F2_SMEM = F2_NST * F2_STAGE;     // 99072 B (the epilogue's 8 x 32 x 68 floats = 69632 B fit inside)
+
+// DBG (timing-only builds behind GNNOPS_GEMM_F32_DBG, wrong results): 1 no DMA inside the loop, 2 no fragment reads inside
+// the loop, 3 no barrier / wait at the top of a K-step — which part of a K-step the matrix pipe waits for.
+template <bool STAGGER, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_f32_dma256_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                                 const float* __restrict__ addend, float* __restrict__ C,
+                                                                 int64_t M, int64_t N, int64_t K, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smemf[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;   // 2 x 4 waves: rows wr*128, columns wc*64
+
+    // tile of this workgroup: XCD-contiguous order over column strips of 8 tiles (row-major inside a strip)
+    constexpr int W = 8;
+    const int64_t t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int full_strips = tiles_n / W;
+    const int64_t in_full = (int64_t)full_strips * W * tiles_m;
+    int by, bx;
+    if (t < in_full) {
+        const int64_t strip = t / ((int64_t)W * tiles_m), r = t % ((int64_t)W * tiles_m);
+        by = (int)(r / W);
+        bx = (int)(strip * W + r % W);
+    } else {
+        const int wl = tiles_n - full_strips * W;
+        const int64_t r = t - in_full;
+        by = (int)(r / wl);
+        bx = full_strips * W + (int)(r % wl);
+    }
+    const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * 256;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's DMA pieces per stage: A pieces 2w, 2w+1 (16 rows x 64 B each), B rows 2w, 2w+1 (1 KiB each)
+    const float* a_src[2];
+    const float* b_src[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int ar = (wave * 2 + p) * 16 + (lane >> 2);
+        const int64_t arow = (m0 + ar < M) ? m0 + ar : M - 1;            // in-bounds filler: the epilogue drops those rows
+        a_src[p] = A + arow * K + (((lane & 3) ^ a4_swz(ar)) << 2);
+        int64_t bcol = n0 + lane * 4;
+        if (bcol > N - 4) bcol = N - 4;                                    // filler columns, dropped by the epilogue
+        b_src[p] = Bm + (int64_t)(wave * 2 + p) * N + bcol;
+    }
+    auto dma = [&](int stage, int64_t k0) {
+        unsigned char* base = smemf + stage * F2_STAGE;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + (wave * 2 + p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * N),
+                                             (__attribute__((address_space(3))) void*)(base + F2_A_BYTES + (wave * 2 + p) * F2_BROW),
+                                             16, 0, 0);
+        }
+    };
+
+    const int a_row = wr * 128 + (lane & 15);
+    const int q = lane >> 4;
+    const int64_t ksteps = K / F2_BK;
+    dma(0, 0);
+    if (ksteps > 1) dma(1, F2_BK);
+    f32x4 af[8], af2[8];
+    float bf[4][4], bf2[4][4];
+    auto read_into = [&](int64_t kt, f32x4 (&fa)[8], float (&fb)[4][4]) {
+        const unsigned char* sA = smemf + (int)(kt % F2_NST) * F2_STAGE;
+        const unsigned char* sB = sA + F2_A_BYTES;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) fa[mi] = *reinterpret_cast<const f32x4*>(sA + a4_off(a_row + mi * 16, q));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                fb[ni][j] = *reinterpret_cast<const float*>(sB + (4 * q + j) * F2_BROW + (wc * 64 + ni * 16 + (lane & 15)) * 4);
+    };
+    auto mfma_from = [&](int j0, const f32x4 (&fa)[8], const float (&fb)[4][4]) {
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+    };
+    auto read_frags = [&](int64_t kt) { read_into(kt, af, bf); };
+    auto mfma_half = [&](int j0) { mfma_from(j0, af, bf); };
+    if constexpr (DBG == 5) {
+        // REGISTER-STAGED operands: global_load_dwordx4 into registers right after the fragment reads, ds_write_b128 after the
+        // MFMAs. Same LDS image (the swizzle is on the source address, the write goes to piece * 1 KiB + lane * 16 B). A
+        // global_load_lds instruction costs the issuing wave ~100 cycles of issue during which it feeds no MFMA
+        // (MI355X_MICROARCH.md "LDS-DMA piece issue cost"); a dwordx4 load ~4 and a ds_write_b128 ~13.
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 ra[2], rb[2];
+        auto gload = [&](int64_t k0) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                ra[p] = *reinterpret_cast<const f4*>(a_src[p] + k0);
+                rb[p] = *reinterpret_cast<const f4*>(b_src[p] + k0 * N);
+            }
+        };
+        auto swrite = [&](int stage) {
+            unsigned char* base = smemf + stage * F2_STAGE;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                *reinterpret_cast<f4*>(base + (wave * 2 + p) * 1024 + lane * 16) = ra[p];
+                *reinterpret_cast<f4*>(base + F2_A_BYTES + (wave * 2 + p) * F2_BROW + lane * 16) = rb[p];
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two tiles the DMA prologue fetched
+        for (int64_t kt = 0; kt < ksteps; ++kt) {
+            __syncthreads();
+            read_frags(kt);
+            const bool more = kt + 2 < ksteps;
+            if (more) gload((kt + 2) * F2_BK);
+            mfma_half(0);
+            mfma_half(2);
+            if (more) swrite((int)((kt + 2) % F2_NST));
+        }
+    } else if constexpr (DBG == 4) {
+        // SOFTWARE-PIPELINED fragments: the barrier for tile kt+1 and its fragment reads (into the second register set) sit
+        // in the MIDDLE of tile kt's MFMA block, so the burst of LDS reads all eight waves issue behind a barrier
+        // (~600 LDS cycles for 8 x 16 reads) runs under the second half's 64 MFMAs instead of in front of an idle pipe.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        read_into(0, af, bf);
+        auto step = [&](int64_t kt, f32x4 (&ca)[8], float (&cb)[4][4], f32x4 (&na)[8], float (&nb)[4][4]) {
+            mfma_from(0, ca, cb);
+            if (kt + 1 < ksteps) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1: issued one K-step ago
+                __syncthreads();
+                read_into(kt + 1, na, nb);
+                if (kt + 2 < ksteps) dma((int)((kt + 2) % F2_NST), (kt + 2) * F2_BK);   // stage of tile kt-1: read a K-step ago
+            }
+            mfma_from(2, ca, cb);
+        };
+        int64_t kt = 0;
+        for (; kt + 1 < ksteps; kt += 2) {
+            step(kt, af, bf, af2, bf2);
+            step(kt + 1, af2, bf2, af, bf);
+        }
+        if (kt < ksteps) step(kt, af, bf, af2, bf2);
+    } else
+    if constexpr (!STAGGER) {
+        for (int64_t kt = 0; kt < ksteps; ++kt) {
+            if (DBG != 3) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tiles kt (and kt+1: a whole K-step old)
+                __syncthreads();                                    // everyone's pieces landed; everyone is done reading tile kt-1
+            }
+            if (DBG != 2 || kt == 0) read_frags(kt);
+            if (DBG != 1 && kt + 2 < ksteps) dma((int)((kt + 2) % F2_NST), (kt + 2) * F2_BK);   // its stage was read in step kt-1
+            mfma_half(0);
+            mfma_half(2);
+        }
+    } else {
+        // PING-PONG: wave w and wave w+4 share a SIMD. Waves 4-7 run half a K-step behind waves 0-3: in every phase one
+        // of the two does its memory work (wait, barrier, fragment reads, four DMA instructions — each ~100 cycles of
+        // issue during which the wave feeds no MFMA) and the first 64 MFMAs of its tile, while its partner issues the last
+        // 64 MFMAs of ITS tile back to back; in lockstep both partners stalled at the same time and the matrix pipe idled
+        // ~12 % of a K-step. One barrier per phase. A wave waits for its own DMA pieces (vmcnt(0)) before the barrier
+        // that opens its memory phase: pieces of tile t are issued two of the wave's memory phases earlier and are
+        // visible to everyone from the barrier after the wave's NEXT memory phase on — before any wave reads tile t.
+        // The two groups run the same loop body, shifted by one barrier: b0 | G0: mem(0) + first half | b1 | G0: second
+        // half, G1: mem(0) + first half | b2 | G0: mem(1) + first half, G1: second half | ... Every wave passes the same
+        // number of barriers (2 * ksteps + 1).
+        const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+        if (grp == 1) {                                             // b0: waves 4-7 start one phase late
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (their pieces of tiles 0 and 1 are waited for here)
+            __syncthreads();
+        }
+        for (int64_t kt = 0; kt < ksteps; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            read_frags(kt);
+            if (kt + 2 < ksteps) dma((int)((kt + 2) % F2_NST), (kt + 2) * F2_BK);
+            mfma_half(0);
+            // phase boundary only: no wait here (a `__syncthreads()` would wait vmcnt(0) for the DMA issued half a K-step
+            // ago). What the protocol needs from this barrier — this wave's fragment reads of tile kt are complete — holds:
+            // the MFMAs above consumed them.
+            asm volatile("s_barrier" ::: "memory");
+            mfma_half(2);
+        }
+        if (grp == 0) asm volatile("s_barrier" ::: "memory");      // the barrier waves 4-7 opened their last half with
+    }
+    __syncthreads();   // the stages are free: the epilogue reuses them
+
+    // epilogue: each wave stages its 128 x 64 tile through LDS in four rounds of 32 rows and writes 16-B row pieces
+    float* ctile = reinterpret_cast<float*>(smemf) + wave * (32 * CS);
+    const bool vec_c = (N % 4 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
+    const int pr = lane >> 4, pc = (lane & 15) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ctile[(h * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[c * 2 + h][ni][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int rr = pass * 4 + pr;
+            const int64_t row = m0 + wr * 128 + c * 32 + rr;
+            const int64_t col = n0 + wc * 64 + pc;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
+            if (row >= M || col >= N) continue;
+            if (vec_c && col + 4 <= N) {
+                if (addend) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * N + col);
+                    v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];
+                }
+                *reinterpret_cast<f32x4*>(C + row * N + col) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * N + col + i] : 0.f);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int ALIGN>
 __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                 int64_t ld, int64_t rows_out) {
@@ -950,6 +1193,37 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
     if (dtype == GNNOPS_F32) {
         const bool a_vec = (K % 4 == 0) && ((uintptr_t)mat1 % 16 == 0);
         const bool b_vec = (N % 4 == 0) && ((uintptr_t)mat2 % 16 == 0);
+        // big problems with whole K-steps and 16-B aligned rows: 256 x 256 tiles staged by LDS-DMA (GNNOPS_GEMM_F32_BIG=0: off)
+        const int64_t tm = gnnops_cdiv(M, 256), tn = gnnops_cdiv(N, 256);
+        const char* big = getenv("GNNOPS_GEMM_F32_BIG");
+        if (a_vec && b_vec && K % F2_BK == 0 && K >= 2 * F2_BK && N >= 4 && tm * tn >= 128 && tm * tn < ((int64_t)1 << 31) &&
+            !(big && big[0] == '0')) {
+            static bool configured = false;
+            if (!configured) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma256_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma256_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM) != hipSuccess)
+                    return gnnops_check_launch("addmm f32 attribute");
+                configured = true;
+            }
+            const char* dbg = getenv("GNNOPS_GEMM_F32_DBG");
+            if (dbg && dbg[0] >= '1' && dbg[0] <= '5') {
+                auto kfn = dbg[0] == '1' ? &gemm_f32_dma256_kernel<false, 1> : dbg[0] == '2' ? &gemm_f32_dma256_kernel<false, 2>
+                           : dbg[0] == '3' ? &gemm_f32_dma256_kernel<false, 3> : dbg[0] == '4' ? &gemm_f32_dma256_kernel<false, 4>
+                           : &gemm_f32_dma256_kernel<false, 5>;
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM) != hipSuccess)
+                    return gnnops_check_launch("addmm f32 attribute");
+                hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), F2_SMEM, stream,
+                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn);
+            } else if (big && big[0] == '1')   // A/B: all eight waves in lockstep (tools/time_gemm_f32.py)
+                hipLaunchKernelGGL(gemm_f32_dma256_kernel<false>, dim3((unsigned)(tm * tn)), dim3(512), F2_SMEM, stream,
+                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn);
+            else
+                hipLaunchKernelGGL(gemm_f32_dma256_kernel<true>, dim3((unsigned)(tm * tn)), dim3(512), F2_SMEM, stream,
+                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn);
+            return gnnops_check_launch("addmm f32 256");
+        }
         dim3 fgrid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
         hipLaunchKernelGGL(gemm_f32_kernel, fgrid, dim3(256), 0, stream, (const float*)mat1, (const float*)mat2,
                            (const float*)input, (float*)out, M, N, K, a_vec, b_vec);

@@ -156,6 +156,31 @@ def test_addmm_fp32(gnnops, M, N, K):
     assert torch.equal(gnnops.matmul(Bi.cuda(), torch.eye(n).cuda()).cpu(), Bi)
 
 
+@pytest.mark.parametrize("M,N,K", [(3072, 3072, 64), (4096, 2048, 512), (2905, 3332, 272), (4099, 2820, 48), (8192, 4096, 32),
+                                   (3000, 3100, 1040)])
+def test_addmm_fp32_big_tiles(gnnops, M, N, K):
+    """>= 128 tiles of 256 x 256, K a multiple of 16, N a multiple of 4: the LDS-DMA fp32 kernel (gemm_f32_dma256_kernel) —
+    XCD-contiguous strip order (a last strip narrower than 8 tiles), filler rows and columns, K-steps 2 .. 65, the k
+    permutation inside a K-step. Same bound as test_addmm_fp32; products with an identity and a row selector exact; and
+    bit-identical results from the 128 x 128 kernel would be too strong (different order of the sum over k)."""
+    g = torch.Generator().manual_seed(34)
+    A = torch.rand(M, K, generator=g) * 2 - 1
+    B = torch.rand(K, N, generator=g) * 2 - 1 + torch.arange(N).float().view(1, N) / N
+    C = torch.rand(M, N, generator=g) * 2 - 1
+    bound = 2 * K * 2.0 ** -24 * (A.double().abs() @ B.double().abs() + C.double().abs()) + 1e-30
+    for inp in (C, None):
+        got = (gnnops.addmm(inp.cuda(), A.cuda(), B.cuda()) if inp is not None else gnnops.matmul(A.cuda(), B.cuda())).cpu().double()
+        ref = A.double() @ B.double() + (inp.double() if inp is not None else 0)
+        assert ((got - ref).abs() <= bound).all(), ((got - ref).abs() / bound).max()
+    # every k and every (row, column) position lands where it should: a selector matrix picks rows of an integer matrix
+    Kb = 1040 if K == 1040 else 256
+    Bi = (torch.arange(Kb * N).view(Kb, N) % 1009).float()
+    sel = torch.randint(0, Kb, (M,), generator=g)
+    S = torch.zeros(M, Kb)
+    S[torch.arange(M), sel] = 1
+    assert torch.equal(gnnops.matmul(S.cuda(), Bi.cuda()).cpu(), Bi[sel])
+
+
 def test_aten_sparse_and_scatter_reduce_overrides(gnnops, monkeypatch):
     """torch.sparse.mm, Tensor.coalesce() and Tensor.scatter_(reduce=...) reach our kernels when the build accepts the
     SparseCUDA registrations (otherwise the by-name entry points remain): verified by counting calls."""
