@@ -1096,6 +1096,174 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_dma256_kernel(const float* __
     }
 }
 
+// ---- fp32, one wave per SIMD: 256 x 256 block tile, FOUR waves of 128 x 128 --------------------------------------
+// The eight-wave kernel above keeps the matrix pipe busy 87.7 % of the cycles (PMC, profiles/round2_d_gemm_f32_pmc.txt): all
+// eight waves read their fragments in one burst behind each barrier (~600 LDS cycles per 8192 MFMA cycles) and two waves
+// of 256 registers have no room to double-buffer them. Here a wave owns a whole SIMD and its 512-register file: 256
+// accumulator registers (8 x 8 MFMA tiles), two sets of fragments (A 8 x b128, B 8 x 4 scalars: 64 registers each). The
+// barrier for tile t+1, its fragment reads and the DMA of tile t+2 sit in the MIDDLE of tile t's 256 MFMAs, the DMA
+// instructions spread between MFMA groups, so nothing the wave waits for is on the critical path of the matrix pipe.
+// Same stages, LDS images, k-permutation and tile order as gemm_f32_dma256_kernel; LDS traffic per K-step is 64 KiB
+// instead of 96 (128 x 128 wave tiles).
+constexpr int W4_CS = 132;   // epilogue row stride in floats (128 + 4)
+
+__global__ __launch_bounds__(256, 1) void gemm_f32_w4_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                             const float* __restrict__ addend, float* __restrict__ C,
+                                                             int64_t M, int64_t N, int64_t K, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smemw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;   // 2 x 2 waves: rows wr*128, columns wc*128
+
+    constexpr int W = 8;
+    const int64_t t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int full_strips = tiles_n / W;
+    const int64_t in_full = (int64_t)full_strips * W * tiles_m;
+    int by, bx;
+    if (t < in_full) {
+        const int64_t strip = t / ((int64_t)W * tiles_m), r = t % ((int64_t)W * tiles_m);
+        by = (int)(r / W);
+        bx = (int)(strip * W + r % W);
+    } else {
+        const int wl = tiles_n - full_strips * W;
+        const int64_t r = t - in_full;
+        by = (int)(r / wl);
+        bx = full_strips * W + (int)(r % wl);
+    }
+    const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * 256;
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's DMA pieces per stage: A pieces 4w .. 4w+3 (16 rows x 64 B each), B rows 4w .. 4w+3 (1 KiB each)
+    const float* a_src[4];
+    const float* b_src[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int ar = (wave * 4 + p) * 16 + (lane >> 2);
+        const int64_t arow = (m0 + ar < M) ? m0 + ar : M - 1;
+        a_src[p] = A + arow * K + (((lane & 3) ^ a4_swz(ar)) << 2);
+        int64_t bcol = n0 + lane * 4;
+        if (bcol > N - 4) bcol = N - 4;
+        b_src[p] = Bm + (int64_t)(wave * 4 + p) * N + bcol;
+    }
+    // LDS-DMA as ONE asm statement (M0 = the wave-uniform LDS destination, written in the statement that reads it —
+    // cdna_hip_programming.md §5.7): as a builtin the compiler drains every outstanding LDS read before it (lgkmcnt(0)) and
+    // every outstanding DMA before the next LDS read (vmcnt(0)); here the protocol below owns both orders.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smemw;
+    auto glds = [&](const float* gsrc, uint32_t lds_dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    auto dma_a = [&](int stage, int64_t k0, int p) { glds(a_src[p] + k0, lds0 + stage * F2_STAGE + (wave * 4 + p) * 1024); };
+    auto dma_b = [&](int stage, int64_t k0, int p) {
+        glds(b_src[p] + k0 * N, lds0 + stage * F2_STAGE + F2_A_BYTES + (wave * 4 + p) * F2_BROW);
+    };
+    auto dma_all = [&](int stage, int64_t k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { dma_a(stage, k0, p); dma_b(stage, k0, p); }
+    };
+
+    const int a_row = wr * 128 + (lane & 15);
+    const int q = lane >> 4;
+    const int64_t ksteps = K / F2_BK;
+    // ONE set of fragment registers in two halves that roll: (a_lo, b_lo) = k-steps j = 0, 1 of a tile, (a_hi, b_hi) =
+    // j = 2, 3. While the MFMAs of one half run, the other half's registers are free and receive what comes next.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 a_lo[8], a_hi[8];
+    float b_lo[8][2], b_hi[8][2];
+    auto read_half = [&](int64_t kt, int h, f32x2 (&fa)[8], float (&fb)[8][2]) {
+        const unsigned char* sA = smemw + (int)(kt % F2_NST) * F2_STAGE;
+        const unsigned char* sB = sA + F2_A_BYTES;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) fa[mi] = *reinterpret_cast<const f32x2*>(sA + a4_off(a_row + mi * 16, q) + h * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+                fb[ni][j] = *reinterpret_cast<const float*>(sB + (4 * q + 2 * h + j) * F2_BROW + (wc * 128 + ni * 16 + (lane & 15)) * 4);
+    };
+    // The 64 accumulator tiles fill the accumulator half of the register file exactly (256 AGPRs). As a builtin the
+    // compiler rotates them through spare registers (D != C plus hundreds of v_accvgpr moves per K-step); as an asm
+    // statement with a read-write "a" operand each tile stays where it is (accumulate chain: no wait states needed
+    // between an MFMA and the next one that takes its D whole as C — cdna_hip_programming.md §5.7 item 2).
+    auto mfma_j = [&](int j, const f32x2 (&fa)[8], const float (&fb)[8][2]) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+                asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[mi][ni]) : "v"(fa[mi][j]), "v"(fb[ni][j]));
+    };
+
+    dma_all(0, 0);
+    if (ksteps > 1) dma_all(1, F2_BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_half(0, 0, a_lo, b_lo);
+    for (int64_t kt = 0; kt < ksteps; ++kt) {
+        read_half(kt, 1, a_hi, b_hi);           // second half of THIS tile: lands under the 128 MFMAs below
+        mfma_j(0, a_lo, b_lo);
+        mfma_j(1, a_lo, b_lo);
+        const bool next = kt + 1 < ksteps, more = kt + 2 < ksteps;
+        const int st2 = (int)((kt + 2) % F2_NST);
+        const int64_t k2 = (kt + 2) * F2_BK;
+        if (next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1: its DMA was issued one K-step ago
+            __syncthreads();                                    // everyone's pieces landed; everyone has read all of tile kt
+            read_half(kt + 1, 0, a_lo, b_lo);                   // first half of the NEXT tile, under the MFMAs below
+        }
+        // the DMA of tile kt+2 (its stage held tile kt-1) between the MFMA groups of the second half. (Staging these
+        // operands through registers instead — dwordx4 loads here, ds_write_b128 after the last MFMA — measured SLOWER:
+        // 117.6 vs 122.5 TFLOP/s at 8192^3, profiles/round2_d_gemm_f32_variants.txt.)
+        if (more) { dma_a(st2, k2, 0); dma_b(st2, k2, 0); dma_a(st2, k2, 1); dma_b(st2, k2, 1); }
+        mfma_j(0, a_hi, b_hi);
+        if (more) { dma_a(st2, k2, 2); dma_b(st2, k2, 2); dma_a(st2, k2, 3); dma_b(st2, k2, 3); }
+        mfma_j(1, a_hi, b_hi);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // the stages are free: the epilogue reuses them
+
+    // epilogue: each wave stages its 128 x 128 tile through LDS in four rounds of 32 rows and writes 16-B row pieces
+    float* ctile = reinterpret_cast<float*>(smemw) + wave * (32 * W4_CS);
+    const bool vec_c = (N % 4 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
+    const int pr = lane >> 5, pc = (lane & 31) * 4;   // 32 lanes x 4 columns per row, 2 rows per pass
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ctile[(h * 16 + (lane >> 4) * 4 + r) * W4_CS + ni * 16 + (lane & 15)] = acc[c * 2 + h][ni][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) {
+            const int rr = pass * 2 + pr;
+            const int64_t row = m0 + wr * 128 + c * 32 + rr;
+            const int64_t col = n0 + wc * 128 + pc;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rr * W4_CS + pc]);
+            if (row >= M || col >= N) continue;
+            if (vec_c && col + 4 <= N) {
+                if (addend) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * N + col);
+                    v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];
+                }
+                *reinterpret_cast<f32x4*>(C + row * N + col) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * N + col + i] : 0.f);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int ALIGN>
 __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                 int64_t ld, int64_t rows_out) {
@@ -1206,6 +1374,18 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
                                         hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM) != hipSuccess)
                     return gnnops_check_launch("addmm f32 attribute");
                 configured = true;
+            }
+            if (big && big[0] == '4') {   // one wave per SIMD: four waves of 128 x 128 (A/B: tools/time_gemm_f32_dbg.py)
+                static bool cfg4 = false;
+                if (!cfg4) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_w4_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM) != hipSuccess)
+                        return gnnops_check_launch("addmm f32 w4 attribute");
+                    cfg4 = true;
+                }
+                hipLaunchKernelGGL(gemm_f32_w4_kernel, dim3((unsigned)(tm * tn)), dim3(256), F2_SMEM, stream, (const float*)mat1,
+                                   (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn);
+                return gnnops_check_launch("addmm f32 w4");
             }
             const char* dbg = getenv("GNNOPS_GEMM_F32_DBG");
             if (dbg && dbg[0] >= '1' && dbg[0] <= '5') {

@@ -156,13 +156,18 @@ def test_addmm_fp32(gnnops, M, N, K):
     assert torch.equal(gnnops.matmul(Bi.cuda(), torch.eye(n).cuda()).cpu(), Bi)
 
 
+@pytest.mark.parametrize("variant", ["", "1", "4"])
 @pytest.mark.parametrize("M,N,K", [(3072, 3072, 64), (4096, 2048, 512), (2905, 3332, 272), (4099, 2820, 48), (8192, 4096, 32),
                                    (3000, 3100, 1040)])
-def test_addmm_fp32_big_tiles(gnnops, M, N, K):
+def test_addmm_fp32_big_tiles(gnnops, monkeypatch, M, N, K, variant):
     """>= 128 tiles of 256 x 256, K a multiple of 16, N a multiple of 4: the LDS-DMA fp32 kernel (gemm_f32_dma256_kernel) —
     XCD-contiguous strip order (a last strip narrower than 8 tiles), filler rows and columns, K-steps 2 .. 65, the k
     permutation inside a K-step. Same bound as test_addmm_fp32; products with an identity and a row selector exact; and
     bit-identical results from the 128 x 128 kernel would be too strong (different order of the sum over k)."""
+    if variant:   # GNNOPS_GEMM_F32_BIG: "" = default, 1 = eight waves in lockstep, 4 = four waves of 128 x 128 (one per SIMD)
+        monkeypatch.setenv("GNNOPS_GEMM_F32_BIG", variant)
+    else:
+        monkeypatch.delenv("GNNOPS_GEMM_F32_BIG", raising=False)
     g = torch.Generator().manual_seed(34)
     A = torch.rand(M, K, generator=g) * 2 - 1
     B = torch.rand(K, N, generator=g) * 2 - 1 + torch.arange(N).float().view(1, N) / N

@@ -12,6 +12,7 @@ for name, env in (("ping-pong", {}), ("lockstep", {"GNNOPS_GEMM_F32_BIG": "1"}),
                   ("lockstep, no fragment reads in the loop", {"GNNOPS_GEMM_F32_DBG": "2"}), ("lockstep, no barrier / wait", {"GNNOPS_GEMM_F32_DBG": "3"}),
                   ("lockstep, fragments software-pipelined", {"GNNOPS_GEMM_F32_DBG": "4"}),
                   ("lockstep, operands staged through registers", {"GNNOPS_GEMM_F32_DBG": "5"}),
+                  ("four waves of 128 x 128, one per SIMD", {"GNNOPS_GEMM_F32_BIG": "4"}),
                   ("128 x 128 register-staged", {"GNNOPS_GEMM_F32_BIG": "0"})):
     for k in ("GNNOPS_GEMM_F32_BIG", "GNNOPS_GEMM_F32_DBG"):
         os.environ.pop(k, None)
