@@ -67,6 +67,8 @@ SIGNATURES = {
     "gnnops_owner_counts": (_ci, [_vp, _i64, _i64, _ci, _vp, _vp]),
     "gnnops_rowptr_expand": (_ci, [_vp, _i64, _i64, _vp, _vp]),
     "gnnops_sddmm": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _ci, _vp]),
+    "gnnops_edge_reduce": (_ci, [_ci, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _ci, _vp, _ci,
+                                 ctypes.c_float, ctypes.c_float, _ci, _vp]),
     "gnnops_segment_composite": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp]),
     "gnnops_segment_composite_hubs": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp, _sz, _vp]),
     "gnnops_addmm_workspace_bytes": (_sz, [_i64, _i64, _i64]),

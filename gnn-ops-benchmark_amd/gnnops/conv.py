@@ -1,0 +1,362 @@
+"""Single message-passing layers, forward pass: the five layers the reference's app benchmarks time
+(app_bm/benchmark_convs.py:146-246: FiLMConv, GINConv, CGConv, PNAConv, SAGEConv; app_bm/groq_script.py:15-111 holds the
+text of CGConv itself) — SURVEY.md §8(f) rank 4.
+
+Constructor arguments, parameter names and shapes follow torch_geometric.nn.conv (2.0.2, requirements.txt:211), so a
+state_dict moves between the two; the forward is NOT MessagePassing.propagate. A layer here is
+    one dense product  x @ [all the layer's per-node weight blocks]      (gemm.hip, MFMA)
+    one edge pass      gnnops_edge_reduce (csrc/conv.hip): message + aggregation(s) + degree scalers + residual
+    (PNA / GIN / SAGE) one dense product on the aggregate                (gemm.hip)
+because every Linear a message applies to cat([x_i, x_j, e]) splits into per-node products: z W = x_i W_i + x_j W_j + e W_e.
+The [E, .] tensors of propagate (x_i, x_j, z, the messages) never exist.
+
+Forward / inference only (the reference times forward under torch.no_grad(), benchmark_convs.py:53-59): the layers freeze
+their parameters (requires_grad False) when built; a call that would need a gradient raises. Training goes through
+gnnops.layers / gnnops.autograd.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .ops import _dtype_code, _require_gpu, _stream, get_plan
+from .sparse import _coo_rows_cols, _csr_arrays
+
+FUNCTORS = {"copy": 0, "add": 1, "cgconv": 2, "film": 3}
+_PARTS = {"copy": (1, 0, 0), "add": (1, 1, 1), "cgconv": (2, 2, 2), "film": (1, 2, 0)}   # K-wide parts per row of q, p, w
+AGGREGATORS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3, "std": 4}
+SCALERS = {"identity": 0, "amplification": 1, "attenuation": 2, "linear": 3, "inverse_linear": 4}
+
+
+def _rows(t, what, parts, K):
+    """A [rows, >= parts*K] operand whose rows are contiguous runs (column blocks of a wider matrix are fine)."""
+    if t is None:
+        return None, 0
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1) or t.size(1) < parts * K:
+        raise RuntimeError(f"edge_reduce: {what} must be 2-D with unit column stride and at least {parts * K} columns")
+    return t, (t.stride(0) if t.size(0) > 1 else t.size(1))
+
+
+def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=("sum",), scalers=(), avg_deg=None, out=None):
+    """out[i] = [scaler_s(deg_i) * AGGR_a_{(j -> i) in edge_index} f(p[i], q[j], w[e])  for s in scalers for a in aggr].
+
+    edge_index int64 [2, E] = (source j, destination i), PyG's flow="source_to_target". See include/gnnops.h
+    (gnnops_edge_reduce) for the functors. ``out`` may be a column block of a wider buffer (what the layer would cat into).
+    The destination plan (rowptr, perm) and the plan-ordered source ids are cached under the edge_index tensor."""
+    _require_gpu(q, edge_index, p, w, add, out)
+    ops._refuse_grad("edge_reduce", q, p, w, add)
+    edge_index, src_rows, dst_rows = _coo_rows_cols(edge_index, "edge_reduce")
+    nq, np_, nw = _PARTS[functor]
+    if q.dim() != 2 or q.size(1) % nq:
+        raise RuntimeError(f"edge_reduce: q must be [rows, {nq} * K]")
+    K = q.size(1) // nq
+    dt = _dtype_code(q, "edge_reduce")
+    for t in (p, w, add, out):
+        if t is not None and t.dtype != q.dtype:
+            raise RuntimeError("edge_reduce: operands must have the same dtype")
+    if functor == "film" and p is None:
+        raise RuntimeError("edge_reduce: the FiLM message needs p = [beta | gamma]")
+    q, ldq = _rows(q, "q", nq, K)
+    p, ldp = _rows(p, "p", np_, K)
+    w, ldw = _rows(w, "w", nw, K)
+    add, ldadd = _rows(add, "add", 1, K)
+    E = edge_index.size(1)
+    if p is not None and p.size(0) != num_dst or add is not None and add.size(0) != num_dst:
+        raise RuntimeError("edge_reduce: p and add have one row per destination")
+    if w is not None and w.size(0) != E:
+        raise RuntimeError("edge_reduce: w has one row per edge")
+    aggr_ids = [AGGREGATORS[a] for a in aggr]
+    scal_ids = [SCALERS[s] for s in scalers]
+    width = max(len(scal_ids), 1) * len(aggr_ids) * K
+    if out is None:
+        out = torch.empty((num_dst, width), dtype=q.dtype, device=q.device)
+    elif out.size(0) != num_dst:
+        raise RuntimeError("edge_reduce: out has one row per destination")
+    out, ldo = _rows(out, "out", 1, width)
+    avg_log, avg_lin = (1.0, 1.0) if avg_deg is None else (float(avg_deg["log"]), float(avg_deg["lin"]))
+    plan = get_plan(dst_rows, num_dst, owner=edge_index, tag=1)
+    col, _ = _csr_arrays(plan, src_rows, None, owner=edge_index, tag=0) if E else (src_rows, None)
+    c_aggr = (ctypes.c_int * len(aggr_ids))(*aggr_ids)
+    c_scal = (ctypes.c_int * max(len(scal_ids), 1))(*scal_ids)
+    ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    with torch.cuda.device(q.device):
+        rc = _lib.load().gnnops_edge_reduce(FUNCTORS[functor], ptr(q), ldq, ptr(p), ldp, ptr(w), ldw, ptr(add), ldadd,
+                                            plan.rowptr.data_ptr(), plan.perm.data_ptr(), col.data_ptr(), out.data_ptr(), ldo,
+                                            num_dst, E, K, c_aggr, len(aggr_ids), c_scal, len(scal_ids), avg_log, avg_lin, dt,
+                                            _stream())
+    check(rc, "edge_reduce")
+    return out
+
+
+# ---- dense side: every weight block a layer applies per node, as ONE operand of the MFMA product ------------------------
+class _Packed:
+    """Weights of several nn.Linear maps packed for one product, rebuilt only when a parameter changes (identity + version
+    counter of the parameters named in ``params``), so transposes and concatenation are paid once per set of weights.
+
+    side by side (default): x @ [W_0^T | W_1^T | ...] — one input, several maps; bias = the concatenated bias rows
+    stacked  (stack=True) : [h_0 | h_1 | ...] @ [W_0^T ; W_1^T ; ...] — several inputs summed into one output"""
+
+    def __init__(self):
+        self.key = self.weight = self.bias = None
+
+    def get(self, params, blocks, stack=False):
+        """params: the Parameters the blocks are cut from; blocks: [(weight or a column slice of it [out, in], bias or None)]."""
+        # Module.to() / .half() swap a parameter's data without touching its version counter: the pointer and dtype are in the key
+        key = tuple((id(t), t._version, t.data_ptr(), t.dtype) for t in params if t is not None)
+        if key != self.key:
+            with torch.no_grad():
+                if stack:
+                    self.weight = torch.cat([wt.t() for wt, _ in blocks], dim=0).contiguous()
+                    biases = [b for _, b in blocks if b is not None]
+                    self.bias = sum(biases[1:], biases[0]).contiguous() if biases else None
+                else:
+                    self.weight = torch.cat([wt.t() for wt, _ in blocks], dim=1).contiguous()
+                    if any(b is not None for _, b in blocks):
+                        self.bias = torch.cat([b if b is not None else wt.new_zeros(wt.size(0)) for wt, b in blocks]).contiguous()
+                    else:
+                        self.bias = None
+            self.key = key
+        return self.weight, self.bias
+
+
+def _dense(x, packed):
+    """x [N, D_in] @ weight [D_in, W] (+ bias row) on the MFMA kernels (gemm.hip)."""
+    weight, bias = packed
+    return ops.addmm(bias, x, weight) if bias is not None else ops.matmul(x, weight)
+
+
+def _linear(x, lin, cache):
+    return _dense(x, cache.get([lin.weight, lin.bias], [(lin.weight, lin.bias)]))
+
+
+def _pair(x):
+    return x if isinstance(x, (tuple, list)) else (x, x)
+
+
+class _Layer(torch.nn.Module):
+    def _freeze(self):
+        self.requires_grad_(False)
+
+    def _forward_only(self, *tensors):
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                        any(t is not None and t.requires_grad for t in tensors)):
+            raise RuntimeError(f"gnnops.conv.{type(self).__name__} is forward-only: freeze its parameters / call it under "
+                               "torch.no_grad() (training: gnnops.layers, gnnops.autograd)")
+
+
+class GINConv(_Layer):
+    """x'_i = nn((1 + eps) * x_i + sum_j x_j)  (torch_geometric GINConv; benchmark_convs.py:163 GINConv(Linear(11, 2048)))."""
+
+    def __init__(self, nn, eps=0.0, train_eps=False):
+        super().__init__()
+        self.nn = nn
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = torch.nn.Parameter(torch.tensor([float(eps)]))
+        else:
+            self.register_buffer("eps", torch.tensor([float(eps)]))
+        self._packed = _Packed()
+        self._freeze()
+
+    def forward(self, x, edge_index, size=None):
+        x_src, x_dst = _pair(x)
+        self._forward_only(x_src, x_dst)
+        n_dst = x_dst.size(0) if size is None else size[1]
+        eps = float(self.eps)
+        root = x_dst if eps == 0.0 else x_dst * (1.0 + eps)
+        h = edge_reduce("copy", x_src.contiguous(), edge_index, n_dst, add=root.contiguous())
+        return _linear(h, self.nn, self._packed) if isinstance(self.nn, torch.nn.Linear) else self.nn(h)
+
+
+class SAGEConv(_Layer):
+    """x'_i = W_l mean_j x_j + W_r x_i  (torch_geometric SAGEConv; benchmark_convs.py:231 SAGEConv(-1, 2048)).
+    One edge pass writes the mean into the left block of [mean | x]; one product with [W_l^T ; W_r^T] finishes the layer."""
+
+    def __init__(self, in_channels, out_channels, normalize=False, root_weight=True, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.normalize, self.root_weight, self._bias = normalize, root_weight, bias
+        self.lin_l = self.lin_r = None
+        if not (isinstance(in_channels, int) and in_channels < 0):
+            self._build(*((in_channels, in_channels) if isinstance(in_channels, int) else in_channels))
+        self._packed = _Packed()
+
+    def _build(self, in_src, in_dst, like=None):
+        kw = {} if like is None else {"device": like.device, "dtype": like.dtype}
+        self.lin_l = torch.nn.Linear(in_src, self.out_channels, bias=self._bias, **kw)
+        if self.root_weight:
+            self.lin_r = torch.nn.Linear(in_dst, self.out_channels, bias=False, **kw)
+        self._freeze()
+
+    def forward(self, x, edge_index, size=None):
+        x_src, x_dst = _pair(x)
+        if self.lin_l is None:   # in_channels = -1: sized by the first input, like PyG's lazy Linear
+            self._build(x_src.size(1), x_dst.size(1), like=x_src)
+        self._forward_only(x_src, x_dst)
+        n_dst = x_dst.size(0) if size is None else size[1]
+        d_src = x_src.size(1)
+        if self.root_weight:
+            h = torch.empty((n_dst, d_src + x_dst.size(1)), dtype=x_src.dtype, device=x_src.device)
+            h[:, d_src:] = x_dst[:n_dst]
+            edge_reduce("copy", x_src.contiguous(), edge_index, n_dst, aggr=("mean",), out=h[:, :d_src])
+            packed = self._packed.get([self.lin_l.weight, self.lin_r.weight, self.lin_l.bias],
+                                      [(self.lin_l.weight, self.lin_l.bias), (self.lin_r.weight, None)], stack=True)
+        else:
+            h = edge_reduce("copy", x_src.contiguous(), edge_index, n_dst, aggr=("mean",))
+            packed = self._packed.get([self.lin_l.weight, self.lin_l.bias], [(self.lin_l.weight, self.lin_l.bias)])
+        out = _dense(h, packed)
+        return torch.nn.functional.normalize(out, p=2.0, dim=-1) if self.normalize else out
+
+
+class CGConv(_Layer):
+    """x'_i = x_i + sum_j sigmoid(z_ij W_f + b_f) * softplus(z_ij W_s + b_s),  z_ij = [x_i, x_j, e_ij]
+    (app_bm/groq_script.py:15-111; forward :91-102, message :104-109)."""
+
+    def __init__(self, channels, dim=0, aggr="add", batch_norm=False, bias=True):
+        super().__init__()
+        self.channels, self.dim, self.aggr, self.batch_norm = channels, dim, aggr, batch_norm
+        self._ch = (channels, channels) if isinstance(channels, int) else tuple(channels)
+        self.lin_f = torch.nn.Linear(sum(self._ch) + dim, self._ch[1], bias=bias)
+        self.lin_s = torch.nn.Linear(sum(self._ch) + dim, self._ch[1], bias=bias)
+        self.bn = torch.nn.BatchNorm1d(self._ch[1]) if batch_norm else None
+        self._pk_dst, self._pk_src, self._pk_edge = _Packed(), _Packed(), _Packed()
+        self._freeze()
+
+    def forward(self, x, edge_index, edge_attr=None):
+        x_src, x_dst = _pair(x)
+        self._forward_only(x_src, x_dst, edge_attr)
+        c_src, c_dst = self._ch
+        K = c_dst
+        Wf, Ws, bf, bs = self.lin_f.weight, self.lin_s.weight, self.lin_f.bias, self.lin_s.bias
+        params = [Wf, Ws, bf, bs]
+        # the weight columns follow cat([x_i, x_j, e]) (groq_script.py:105-108)
+        dst_blocks = [(Wf[:, :c_dst], bf), (Ws[:, :c_dst], bs)]                                # -> p = [f | s], biases included
+        src_blocks = [(Wf[:, c_dst:c_dst + c_src], None), (Ws[:, c_dst:c_dst + c_src], None)]  # -> q = [f | s]
+        n_dst = x_dst.size(0)
+        if x_src is x_dst:   # one product for both sides: [p | q] = x @ [W_f,i | W_s,i | W_f,j | W_s,j]
+            pq = _dense(x_dst.contiguous(), self._pk_dst.get(params, dst_blocks + src_blocks))
+            p, q = pq[:, :2 * K], pq[:, 2 * K:]
+        else:
+            p = _dense(x_dst.contiguous(), self._pk_dst.get(params, dst_blocks))
+            q = _dense(x_src.contiguous(), self._pk_src.get(params, src_blocks))
+        w = None
+        if edge_attr is not None:
+            if edge_attr.dim() == 1:
+                edge_attr = edge_attr.unsqueeze(-1)
+            w = _dense(edge_attr.contiguous(), self._pk_edge.get(params, [(Wf[:, c_dst + c_src:], None), (Ws[:, c_dst + c_src:], None)]))
+        aggr = "sum" if self.aggr == "add" else self.aggr
+        if self.bn is None:
+            return edge_reduce("cgconv", q, edge_index, n_dst, p=p, w=w, add=x_dst.contiguous(), aggr=(aggr,))
+        out = self.bn(edge_reduce("cgconv", q, edge_index, n_dst, p=p, w=w, aggr=(aggr,)))
+        out += x_dst
+        return out
+
+
+class FiLMConv(_Layer):
+    """x'_i = sum_r mean_{j in N_r(i)} relu(gamma_r,i * W_r x_j + beta_r,i) + relu(gamma_s,i * W_s x_i + beta_s,i)
+    (torch_geometric FiLMConv, aggr="mean", act=ReLU; benchmark_convs.py:146 FiLMConv(in_channels=11, out_channels=2048)).
+    One product gives [beta_s | gamma_s | W_s x | (beta_r | gamma_r | W_r x) for every relation] per node."""
+
+    def __init__(self, in_channels, out_channels, num_relations=1, nn=None, act=torch.nn.ReLU(), aggr="mean"):
+        super().__init__()
+        if nn is not None:
+            raise NotImplementedError("gnnops.conv.FiLMConv: a custom film network is not fused; pass nn=None")
+        if not isinstance(act, torch.nn.ReLU):
+            raise NotImplementedError("gnnops.conv.FiLMConv: act must be ReLU (the edge pass applies it)")
+        if isinstance(in_channels, (tuple, list)):
+            raise NotImplementedError("gnnops.conv.FiLMConv: bipartite input")
+        self.in_channels, self.out_channels, self.num_relations = in_channels, out_channels, max(num_relations, 1)
+        self.act, self.aggr = act, aggr
+        R = self.num_relations
+        self.lins = torch.nn.ModuleList([torch.nn.Linear(in_channels, out_channels, bias=False) for _ in range(R)])
+        self.films = torch.nn.ModuleList([torch.nn.Linear(in_channels, 2 * out_channels) for _ in range(R)])
+        self.lin_skip = torch.nn.Linear(in_channels, out_channels, bias=False)
+        self.film_skip = torch.nn.Linear(in_channels, 2 * out_channels, bias=False)
+        self._packed = _Packed()
+        self._freeze()
+
+    def forward(self, x, edge_index, edge_type=None):
+        if isinstance(x, (tuple, list)):
+            raise NotImplementedError("gnnops.conv.FiLMConv: bipartite input")
+        self._forward_only(x)
+        o, R = self.out_channels, self.num_relations
+        blocks = [(self.film_skip.weight, None), (self.lin_skip.weight, None)]
+        for r in range(R):
+            blocks += [(self.films[r].weight, self.films[r].bias), (self.lins[r].weight, None)]
+        y = _dense(x.contiguous(), self._packed.get(list(self.parameters()), blocks))   # [N, 3 o (1 + R)]
+        beta_s, gamma_s, xs = y[:, :o], y[:, o:2 * o], y[:, 2 * o:3 * o]
+        out = torch.relu_(gamma_s * xs + beta_s)
+        aggr = "sum" if self.aggr == "add" else self.aggr
+        n = x.size(0)
+        for r in range(R):
+            base = 3 * o * (1 + r)     # film(x) = [beta | gamma] (FiLMConv.forward: .split(out_channels, dim=-1)), then W_r x
+            ei = edge_index if R == 1 else edge_index[:, edge_type == r].contiguous()
+            out = edge_reduce("film", y[:, base + 2 * o:base + 3 * o], ei, n, p=y[:, base:base + 2 * o], add=out, aggr=(aggr,))
+        return out
+
+
+class PNAConv(_Layer):
+    """Principal neighbourhood aggregation (torch_geometric PNAConv; benchmark_convs.py:197-206: in 1, out 2048,
+    aggregators mean/min/max/std, scalers identity/amplification/attenuation, deg = in-degree histogram).
+    message = pre_nn([x_i, x_j (, enc(e))]) with ONE pre-layer is p_i + q_j (+ w_e); the aggregators and scalers come out of
+    one edge pass, written next to x into the [N, (1 + A S) F] operand of the post layer."""
+
+    def __init__(self, in_channels, out_channels, aggregators, scalers, deg, edge_dim=None, towers=1, pre_layers=1,
+                 post_layers=1, divide_input=False):
+        super().__init__()
+        if pre_layers != 1 or post_layers != 1:
+            raise NotImplementedError("gnnops.conv.PNAConv: pre_layers and post_layers must be 1 (a deeper pre-MLP is not "
+                                      "linear in [x_i, x_j], so it cannot leave the edge loop)")
+        if divide_input and in_channels % towers or out_channels % towers:
+            raise ValueError("PNAConv: channels must divide by towers")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.aggregators, self.scalers = list(aggregators), list(scalers)
+        self.edge_dim, self.towers, self.divide_input = edge_dim, towers, divide_input
+        self.F_in = in_channels // towers if divide_input else in_channels
+        self.F_out = out_channels // towers
+        deg = deg.to(torch.float)
+        total = deg.sum()
+        bins = torch.arange(deg.numel(), dtype=torch.float)
+        self.avg_deg = {"lin": float((bins * deg).sum() / total), "log": float(((bins + 1).log() * deg).sum() / total),
+                        "exp": float((bins.exp() * deg).sum() / total)}
+        F = self.F_in
+        if edge_dim is not None:
+            self.edge_encoder = torch.nn.Linear(edge_dim, F)
+        self.pre_nns = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear((3 if edge_dim else 2) * F, F)) for _ in range(towers)])
+        width = (len(self.aggregators) * len(self.scalers) + 1) * F
+        self.post_nns = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(width, self.F_out)) for _ in range(towers)])
+        self.lin = torch.nn.Linear(out_channels, out_channels)
+        self._pk = {}
+        self._freeze()
+
+    def _cache(self, name):
+        if name not in self._pk:
+            self._pk[name] = _Packed()
+        return self._pk[name]
+
+    def forward(self, x, edge_index, edge_attr=None):
+        self._forward_only(x, edge_attr)
+        F, T = self.F_in, self.towers
+        n = x.size(0)
+        xt = x.view(n, T, F) if self.divide_input else x.view(n, 1, F).expand(n, T, F)
+        A, S = len(self.aggregators), len(self.scalers)
+        e = None
+        if self.edge_dim is not None:
+            if edge_attr is None:
+                raise RuntimeError("PNAConv: edge_attr is required when edge_dim is set")
+            e = _linear(edge_attr.contiguous(), self.edge_encoder, self._cache("enc"))
+        outs = []
+        for t in range(T):
+            pre, post = self.pre_nns[t][0], self.post_nns[t][0]
+            xin = xt[:, t].contiguous()
+            Wp = pre.weight                                              # [F, 2F or 3F]: columns follow cat([x_i, x_j, e])
+            pq = _dense(xin, self._cache(f"pre{t}").get([Wp, pre.bias], [(Wp[:, :F], pre.bias), (Wp[:, F:2 * F], None)]))
+            w = _dense(e, self._cache(f"edge{t}").get([Wp], [(Wp[:, 2 * F:], None)])) if e is not None else None
+            h = torch.empty((n, (1 + A * S) * F), dtype=x.dtype, device=x.device)
+            h[:, :F] = xin
+            edge_reduce("add", pq[:, F:], edge_index, n, p=pq[:, :F], w=w, aggr=self.aggregators, scalers=self.scalers,
+                        avg_deg=self.avg_deg, out=h[:, F:])
+            outs.append(_linear(h, post, self._cache(f"post{t}")))
+        out = outs[0] if T == 1 else torch.cat(outs, dim=1)
+        return _linear(out, self.lin, self._cache("lin"))

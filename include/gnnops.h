@@ -351,6 +351,34 @@ int gnnops_segment_composite_hubs(const void* src, const int32_t* rowptr, const 
                                   int64_t E, int64_t K, int64_t N, int dtype, int mode, double param,
                                   void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Widening per SURVEY.md 8(f) rank 4: the message + aggregate of one message-passing layer in one pass
+ * (app_bm/benchmark_convs.py:146-246 times FiLMConv, GINConv, CGConv, PNAConv, SAGEConv forward;
+ * app_bm/groq_script.py:91-109 is CGConv.forward / .message). Replaces, per layer, the chain
+ * x[edge_index[0]] / x[edge_index[1]] -> message -> torch_scatter.scatter(..., reduce) of MessagePassing.propagate.
+ *
+ *   out[i, (s * n_aggr + a) * K + k] = scaler_s(deg_i) * AGGR_a over the edges (j -> i) of f(p[i], q[j], w[e])[k]
+ *
+ * Edges in destination-sorted (plan) order: rowptr int32 [N+1]; col int64 [E] = source row j of sorted edge position;
+ * perm int32 [E] = original edge id of that position (only read when w is given; NULL = identity).
+ * functor 0 COPY    f = q                                             rows: q [K]
+ *         1 ADD     f = p + q + w   (p, w optional)                         q, p, w [K]
+ *         2 CGCONV  f = sigmoid(p_f + q_f + w_f) * softplus(p_s + q_s + w_s) q, p, w [f part K | s part K]; p, w optional
+ *         3 FILM    f = relu(gamma * q + beta)                               q [K], p [beta K | gamma K]
+ * aggr[]: 0 sum, 1 mean (divide by max(deg, 1)), 2 min, 3 max (0 for rows without edges), 4 std =
+ *   sqrt(relu(mean(f^2) - mean(f)^2) + 1e-5) — PNAConv.aggregate; scalers[] (n_scalers == 0: none): 0 identity,
+ *   1 amplification log(deg+1)/avg_deg_log, 2 attenuation avg_deg_log/log(deg+1), 3 linear deg/avg_deg_lin,
+ *   4 inverse_linear avg_deg_lin/deg, deg clamped to >= 1 — PNAConv's degree scalers.
+ * add (optional, [N, >=K]): added to the first output block (CGConv's `out += x[1]`).
+ * ld* = row pitches in elements, so operands may be column blocks of one GEMM result and `out` a column block of the
+ * buffer the layer would torch.cat into. fp32 arithmetic, one rounding on store.
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_edge_reduce(int functor, const void* q, int64_t ldq, const void* p, int64_t ldp, const void* w, int64_t ldw,
+                       const void* add, int64_t ldadd, const int32_t* rowptr, const int32_t* perm, const int64_t* col,
+                       void* out, int64_t ldo, int64_t N, int64_t E, int64_t K, const int* aggr, int n_aggr,
+                       const int* scalers, int n_scalers, float avg_deg_log, float avg_deg_lin, int dtype,
+                       gnnops_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
