@@ -52,12 +52,12 @@ __device__ inline int b_off(int row, int ch) { return row * 256 + ((ch ^ (((row 
 // alignment allows (16 B when N % 8 == 0, 8 B when N % 4 == 0, else per element); rows >= M and columns >= N are dropped.
 template <typename T>
 __device__ inline void epi_store8(T* __restrict__ C, const T* __restrict__ addend, int64_t row, int64_t col, int64_t M,
-                                  int64_t N, float (&f)[8], bool vec_c, bool half_c) {
+                                  int64_t N, float (&f)[8], bool vec_c, bool half_c, int64_t ldadd) {
     if (row >= M || col >= N) return;
     if (vec_c && col + 8 <= N) {
         if (addend) {
             float g[8];
-            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + row * N + col), g);
+            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + row * ldadd + col), g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] += g[i];
         }
@@ -68,7 +68,7 @@ __device__ inline void epi_store8(T* __restrict__ C, const T* __restrict__ adden
             if (col + 4 * h < N) {
                 float* fh = f + 4 * h;
                 if (addend) {
-                    const uint2 g2 = *reinterpret_cast<const uint2*>(addend + row * N + col + 4 * h);
+                    const uint2 g2 = *reinterpret_cast<const uint2*>(addend + row * ldadd + col + 4 * h);
                     float g[8];
                     Elem<T>::unpack(u32x4{g2.x, g2.y, 0u, 0u}, g);
 #pragma unroll
@@ -84,7 +84,7 @@ __device__ inline void epi_store8(T* __restrict__ C, const T* __restrict__ adden
         for (int i = 0; i < 8; ++i) {
             if (col + i < N) {
                 float v = f[i];
-                if (addend) v += Elem<T>::load(addend + row * N + col + i);
+                if (addend) v += Elem<T>::load(addend + row * ldadd + col + i);
                 Elem<T>::store(C + row * N + col + i, v);
             }
         }
@@ -92,7 +92,7 @@ __device__ inline void epi_store8(T* __restrict__ C, const T* __restrict__ adden
 }
 
 // 8 consecutive 16-bit elements of row `r`, columns c..c+7 of a [rows][cols] row-major matrix whose rows start
-// ALIGN-byte aligned (cols * 2 % ALIGN == 0): ALIGN = 16 -> one dwordx4, 8 -> two dwordx2, 4 -> four dwords.
+// ALIGN-byte aligned (cols * 2 % ALIGN == 0): ALIGN = 16 -> one dwordx4, 8 -> two dwordx2, 4 -> four dwords, 2 -> elements.
 // A piece never straddles the row end; pieces beyond it, and rows beyond `rows`, read as 0.
 template <int ALIGN>
 __device__ inline u32x4 load8(const uint16_t* __restrict__ base, int64_t r, int64_t c, int64_t rows, int64_t cols) {
@@ -105,11 +105,17 @@ __device__ inline u32x4 load8(const uint16_t* __restrict__ base, int64_t r, int6
         const uint2 lo = *reinterpret_cast<const uint2*>(p);
         v.x = lo.x; v.y = lo.y;
         if (c + 4 < cols) { const uint2 hi = *reinterpret_cast<const uint2*>(p + 4); v.z = hi.x; v.w = hi.y; }
-    } else {
+    } else if constexpr (ALIGN == 4) {
         v.x = *reinterpret_cast<const uint32_t*>(p);
         if (c + 2 < cols) v.y = *reinterpret_cast<const uint32_t*>(p + 2);
         if (c + 4 < cols) v.z = *reinterpret_cast<const uint32_t*>(p + 4);
         if (c + 6 < cols) v.w = *reinterpret_cast<const uint32_t*>(p + 6);
+    } else {   // odd row lengths (K = 11 node features): element loads
+        uint16_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (c + j < cols) ? p[j] : (uint16_t)0;
+        v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+        v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
     }
     return v;
 }
@@ -119,7 +125,7 @@ __device__ inline u32x4 load8(const uint16_t* __restrict__ base, int64_t r, int6
 template <typename T, bool IS_BF16, int ALIGN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
                                                       const T* __restrict__ addend, T* __restrict__ C, int64_t M,
-                                                      int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+                                                      int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd) {
     // lda / ldb = row lengths as stored (== K / N unless the host padded them); they bound the column reads
     constexpr int EPI_BYTES = 4 * 64 * CS * 4;  // four waves' fp32 tiles
     constexpr int SMEM_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint16_t* __restrict
         const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
         f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c);
+        epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c, ldadd);
     }
 }
 
@@ -262,7 +268,7 @@ __device__ inline int a4_off(int row, int ch) { return row * 64 + ((ch ^ a4_swz(
 template <typename T, bool IS_BF16>
 __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
                                                            const T* __restrict__ addend, T* __restrict__ C, int64_t M,
-                                                           int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+                                                           int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd) {
     constexpr int EPI_BYTES = 4 * 64 * CS * 4;
     constexpr int SMEM_BYTES = (NST * STAGE4_BYTES > EPI_BYTES) ? NST * STAGE4_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
@@ -392,9 +398,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
     const bool pre_ok = vec_c && addend != nullptr && m0 + BM <= M && n0 + BN <= N;
     u32x4 pre[8];
     if (pre_ok) {
-        const T* ap = addend + (m0 + wr * 64 + pr) * N + n0 + wc * 64 + pc;
+        const T* ap = addend + (m0 + wr * 64 + pr) * ldadd + n0 + wc * 64 + pc;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pre[i] = *reinterpret_cast<const u32x4*>(ap + (int64_t)i * 8 * N);
+        for (int i = 0; i < 8; ++i) pre[i] = *reinterpret_cast<const u32x4*>(ap + (int64_t)i * 8 * ldadd);
     }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
             for (int i = 0; i < 8; ++i) f[i] += g[i];
             *reinterpret_cast<u32x4*>(C + row * N + col) = Elem<T>::pack(f);
         } else {
-            epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c);
+            epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c, ldadd);
         }
     }
 }
@@ -432,7 +438,7 @@ constexpr int EPI2_ROWS = 32;  // rows of a wave's 128 staged per epilogue round
 template <typename T, bool IS_BF16, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
                                                              const T* __restrict__ addend, T* __restrict__ C, int64_t M,
-                                                             int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+                                                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
     unsigned char* smem = smem256;
 
@@ -670,9 +676,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
     const bool pre_ok = vec_c && addend != nullptr && m0 + BM2 <= M && n0 + BN2 <= N;
     u32x4 pre[16];
     if (pre_ok) {
-        const T* ap = addend + (m0 + wr * 128 + pr) * N + n0 + wc * 64 + pc;
+        const T* ap = addend + (m0 + wr * 128 + pr) * ldadd + n0 + wc * 64 + pc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const u32x4*>(ap + (int64_t)i * 8 * N);
+        for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const u32x4*>(ap + (int64_t)i * 8 * ldadd);
     }
 #pragma unroll
     for (int c = 0; c < 128 / EPI2_ROWS; ++c) {
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
                 for (int i = 0; i < 8; ++i) f[i] += g[i];
                 *reinterpret_cast<u32x4*>(C + row * N + col) = Elem<T>::pack(f);
             } else {
-                epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c);
+                epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c, ldadd);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -708,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
 
 template <typename T, bool IS_BF16, int VAR>
 int launch_dma256_var(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K,
-                  int64_t lda, int64_t ldb, hipStream_t stream) {
+                  int64_t lda, int64_t ldb, int64_t ldadd, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma256_kernel<T, IS_BF16, VAR>),
@@ -718,16 +724,16 @@ int launch_dma256_var(const void* input, const void* mat1, const void* mat2, voi
     }
     hipLaunchKernelGGL((gemm_dma256_kernel<T, IS_BF16, VAR>), dim3((unsigned)gnnops_cdiv(N, BN2), (unsigned)gnnops_cdiv(M, BM2)), dim3(512),
                        GEMM256_SMEM, stream, (const uint16_t*)mat1, (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K,
-                       lda, ldb);
+                       lda, ldb, ldadd);
     return gnnops_check_launch("addmm");
 }
 
 template <typename T, bool IS_BF16>
 int launch_dma256(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K,
-                  int64_t lda, int64_t ldb, hipStream_t stream) {
+                  int64_t lda, int64_t ldb, int64_t ldadd, hipStream_t stream) {
     const char* var = getenv("GNNOPS_GEMM_VAR");
-    if (var && var[0] == '1') return launch_dma256_var<T, IS_BF16, 1>(input, mat1, mat2, out, M, N, K, lda, ldb, stream);
-    return launch_dma256_var<T, IS_BF16, 2>(input, mat1, mat2, out, M, N, K, lda, ldb, stream);
+    if (var && var[0] == '1') return launch_dma256_var<T, IS_BF16, 1>(input, mat1, mat2, out, M, N, K, lda, ldb, ldadd, stream);
+    return launch_dma256_var<T, IS_BF16, 2>(input, mat1, mat2, out, M, N, K, lda, ldb, ldadd, stream);
 }
 
 // ---- fp32 operands: v_mfma_f32_16x16x4_f32 (exact fp32 products and sums, 1/16 of the bf16 MFMA rate = the fp32
@@ -749,7 +755,7 @@ __device__ inline f32x4 load4f(const float* __restrict__ base, int64_t r, int64_
 
 __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                           const float* __restrict__ addend, float* __restrict__ C,
-                                                          int64_t M, int64_t N, int64_t K, bool a_vec, bool b_vec) {
+                                                          int64_t M, int64_t N, int64_t K, bool a_vec, bool b_vec, int64_t ldadd) {
     constexpr int STAGE_F = BM * FAS + FBK * FBS;       // floats per stage (2560 + 2304)
     constexpr int EPI_F = 4 * 32 * CS;
     constexpr int SMEM_F = (2 * STAGE_F > EPI_F) ? 2 * STAGE_F : EPI_F;
@@ -839,14 +845,14 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
             if (row >= M || col >= N) continue;
             if (vec_c && col + 4 <= N) {
                 if (addend) {
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * N + col);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * ldadd + col);
                     v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];
                 }
                 *reinterpret_cast<f32x4*>(C + row * N + col) = v;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * N + col + i] : 0.f);
+                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * ldadd + col + i] : 0.f);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -878,7 +884,7 @@ constexpr int F2_SMEM = F2_NST * F2_STAGE;     // 99072 B (the epilogue's 8 x 32
 template <bool STAGGER, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_f32_dma256_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                                  const float* __restrict__ addend, float* __restrict__ C,
-                                                                 int64_t M, int64_t N, int64_t K, int tiles_m, int tiles_n) {
+                                                                 int64_t M, int64_t N, int64_t K, int tiles_m, int tiles_n, int64_t ldadd) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smemf[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;   // 2 x 4 waves: rows wr*128, columns wc*64
@@ -1082,14 +1088,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_dma256_kernel(const float* __
             if (row >= M || col >= N) continue;
             if (vec_c && col + 4 <= N) {
                 if (addend) {
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * N + col);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * ldadd + col);
                     v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];
                 }
                 *reinterpret_cast<f32x4*>(C + row * N + col) = v;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * N + col + i] : 0.f);
+                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * ldadd + col + i] : 0.f);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1109,7 +1115,7 @@ constexpr int W4_CS = 132;   // epilogue row stride in floats (128 + 4)
 
 __global__ __launch_bounds__(256, 1) void gemm_f32_w4_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                              const float* __restrict__ addend, float* __restrict__ C,
-                                                             int64_t M, int64_t N, int64_t K, int tiles_m, int tiles_n) {
+                                                             int64_t M, int64_t N, int64_t K, int tiles_m, int tiles_n, int64_t ldadd) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smemw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1250,14 +1256,14 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_w4_kernel(const float* __rest
             if (row >= M || col >= N) continue;
             if (vec_c && col + 4 <= N) {
                 if (addend) {
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * N + col);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(addend + row * ldadd + col);
                     v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];
                 }
                 *reinterpret_cast<f32x4*>(C + row * N + col) = v;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * N + col + i] : 0.f);
+                    if (col + i < N) C[row * N + col + i] = v[i] + (addend ? addend[row * ldadd + col + i] : 0.f);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1329,14 +1335,15 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
         g.a_bytes = g.copy_a ? align_up((size_t)M * g.lda * 2, 256) : 0;
         g.b_bytes = g.copy_b ? align_up((size_t)g.Kp * g.ldb * 2, 256) : 0;
     } else {
+        // register staging bounds-checks every piece and reads rows of any length in the widest pieces their alignment
+        // allows (load8<ALIGN>): no copies — these are the small, launch-bound problems (a batch of small graphs:
+        // [9134, 11] @ [11, 44]), where two pad launches cost more than the product
         g.path = 0;
         g.Kp = K;
-        g.copy_a = K % 8 != 0 && K > 0;
-        g.copy_b = N % 8 != 0 && K > 0;
-        g.lda = round_up(K, 8);
-        g.ldb = round_up(N, 8);
-        g.a_bytes = g.copy_a ? align_up((size_t)M * g.lda * 2, 256) : 0;
-        g.b_bytes = g.copy_b ? align_up((size_t)K * g.ldb * 2, 256) : 0;
+        g.copy_a = g.copy_b = false;
+        g.lda = K;
+        g.ldb = N;
+        g.a_bytes = g.b_bytes = 0;
     }
     return g;
 }
@@ -1351,13 +1358,32 @@ extern "C" size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K) 
 
 extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N,
                             int64_t K, int dtype, void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
+    return gnnops_addmm_ld(input, N, mat1, mat2, out, M, N, K, dtype, workspace, workspace_bytes, s);
+}
+
+extern "C" int gnnops_addmm_ld(const void* input, int64_t ldadd, const void* mat1, const void* mat2, void* out, int64_t M,
+                               int64_t N, int64_t K, int dtype, void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(M >= 0 && N >= 0 && K >= 0, GNNOPS_EINVAL, "addmm: negative size");
     GNNOPS_REQUIRE(dtype == GNNOPS_F16 || dtype == GNNOPS_BF16 || dtype == GNNOPS_F32, GNNOPS_EUNSUPPORTED,
                    "addmm: unknown dtype code %d", dtype);
+    GNNOPS_REQUIRE(ldadd == 0 || ldadd >= N, GNNOPS_EINVAL, "addmm: input row pitch must be 0 (one row for all) or >= N");
     if (M * N == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(out && (K == 0 || (mat1 && mat2)), GNNOPS_EINVAL, "addmm: null pointer");
-    GNNOPS_REQUIRE(gnnops_cdiv(M, BM) < 65536, GNNOPS_EUNSUPPORTED, "addmm: M too large for the grid");
+    // the row-tile index travels in gridDim.y (< 65536): taller problems (a node-feature matrix of BASELINE config 2's
+    // 10M rows) run as slabs of whole tiles, one after the other on the stream, sharing the workspace
+    constexpr int64_t SLAB = (int64_t)65280 * BM;
+    if (M > SLAB) {
+        const size_t es = dtype == GNNOPS_F32 ? 4 : 2;
+        for (int64_t r0 = 0; r0 < M; r0 += SLAB) {
+            const int64_t rows = M - r0 < SLAB ? M - r0 : SLAB;
+            const int rc = gnnops_addmm_ld(input ? (const char*)input + (size_t)r0 * ldadd * es : nullptr, ldadd,
+                                           (const char*)mat1 + (size_t)r0 * K * es, mat2, (char*)out + (size_t)r0 * N * es, rows, N, K,
+                                           dtype, workspace, workspace_bytes, s);
+            if (rc != GNNOPS_OK) return rc;
+        }
+        return GNNOPS_OK;
+    }
     if (dtype == GNNOPS_F32) {
         const bool a_vec = (K % 4 == 0) && ((uintptr_t)mat1 % 16 == 0);
         const bool b_vec = (N % 4 == 0) && ((uintptr_t)mat2 % 16 == 0);
@@ -1384,7 +1410,7 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
                     cfg4 = true;
                 }
                 hipLaunchKernelGGL(gemm_f32_w4_kernel, dim3((unsigned)(tm * tn)), dim3(256), F2_SMEM, stream, (const float*)mat1,
-                                   (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn);
+                                   (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn, ldadd);
                 return gnnops_check_launch("addmm f32 w4");
             }
             const char* dbg = getenv("GNNOPS_GEMM_F32_DBG");
@@ -1395,18 +1421,18 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM) != hipSuccess)
                     return gnnops_check_launch("addmm f32 attribute");
                 hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), F2_SMEM, stream,
-                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn);
+                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn, ldadd);
             } else if (big && big[0] == '1')   // A/B: all eight waves in lockstep (tools/time_gemm_f32.py)
                 hipLaunchKernelGGL(gemm_f32_dma256_kernel<false>, dim3((unsigned)(tm * tn)), dim3(512), F2_SMEM, stream,
-                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn);
+                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn, ldadd);
             else
                 hipLaunchKernelGGL(gemm_f32_dma256_kernel<true>, dim3((unsigned)(tm * tn)), dim3(512), F2_SMEM, stream,
-                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn);
+                                   (const float*)mat1, (const float*)mat2, (const float*)input, (float*)out, M, N, K, (int)tm, (int)tn, ldadd);
             return gnnops_check_launch("addmm f32 256");
         }
         dim3 fgrid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
         hipLaunchKernelGGL(gemm_f32_kernel, fgrid, dim3(256), 0, stream, (const float*)mat1, (const float*)mat2,
-                           (const float*)input, (float*)out, M, N, K, a_vec, b_vec);
+                           (const float*)input, (float*)out, M, N, K, a_vec, b_vec, ldadd);
         return gnnops_check_launch("addmm f32");
     }
     const GemmPlan g = gemm_plan(M, N, K);
@@ -1426,27 +1452,41 @@ extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat
         launch_pad(mat2, w, K, N, ldb, g.Kp, stream);  // rows K .. Kp-1 zero
         mat2 = w;
     }
-    GNNOPS_REQUIRE(K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0), GNNOPS_EUNSUPPORTED,
+    GNNOPS_REQUIRE(g.path == 0 || K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0), GNNOPS_EUNSUPPORTED,
                    "addmm: operand base pointers must be 16-byte aligned");
     if (g.path == 2)
         return dtype == GNNOPS_BF16
-                   ? launch_dma256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, stream)
-                   : launch_dma256<__half, false>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, stream);
+                   ? launch_dma256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, stream)
+                   : launch_dma256<__half, false>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, stream);
     dim3 grid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
     if (g.path == 1) {
         if (dtype == GNNOPS_BF16)
             hipLaunchKernelGGL((gemm_dma4_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, g.Kp, lda, ldb);
+                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, g.Kp, lda, ldb, ldadd);
         else
             hipLaunchKernelGGL((gemm_dma4_kernel<__half, false>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, g.Kp, lda, ldb);
+                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, g.Kp, lda, ldb, ldadd);
         return gnnops_check_launch("addmm");
     }
-    if (dtype == GNNOPS_BF16)
-        hipLaunchKernelGGL((gemm_kernel<__hip_bfloat16, true, 16>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                           (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb);
-    else
-        hipLaunchKernelGGL((gemm_kernel<__half, false, 16>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                           (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb);
+    // path 0: the widest piece both operands' rows allow
+    int align = 16;
+    for (; align > 2; align >>= 1)
+        if ((K * 2) % align == 0 && (N * 2) % align == 0 && (uintptr_t)mat1 % align == 0 && (uintptr_t)mat2 % align == 0) break;
+#define GNNOPS_GEMM0(AL)                                                                                                        \
+    do {                                                                                                                        \
+        if (dtype == GNNOPS_BF16)                                                                                               \
+            hipLaunchKernelGGL((gemm_kernel<__hip_bfloat16, true, AL>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,     \
+                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, K, lda, ldb, ldadd); \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((gemm_kernel<__half, false, AL>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,             \
+                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, K, lda, ldb, ldadd);             \
+    } while (0)
+    switch (align) {
+        case 16: GNNOPS_GEMM0(16); break;
+        case 8: GNNOPS_GEMM0(8); break;
+        case 4: GNNOPS_GEMM0(4); break;
+        default: GNNOPS_GEMM0(2); break;
+    }
+#undef GNNOPS_GEMM0
     return gnnops_check_launch("addmm");
 }

@@ -13,6 +13,7 @@
 // The same engine sorts fp32 keys for torch.sort (sort.hip) and 64-bit COO keys for coalesce.
 #include "common.h"
 #include "sort_engine.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -104,6 +105,77 @@ __global__ void fill_gaps_kernel(int32_t* __restrict__ rowptr, const int32_t* __
         int64_t lo = gap_list[3 * (int64_t)g + 0], hi = gap_list[3 * (int64_t)g + 1];
         int32_t v = gap_list[3 * (int64_t)g + 2];
         for (int64_t n = lo + threadIdx.x; n <= hi; n += blockDim.x) rowptr[n] = v;
+    }
+}
+
+
+// ---- small inputs: the whole plan in ONE launch -----------------------------------------------------------------------
+// The radix build above is ten launches (memset, 2 x (hist, scan, scatter), rowptr, fill_gaps + the caller's permute of the
+// companion column): ~45 us of kernels but ~90 us of launch overhead, which is all a batch of small graphs costs
+// (app_bm/benchmark_convs.py: 512 QM9 molecules = 9 134 nodes, 18 744 edges). Up to 65 536 positions and 40 000
+// destinations ONE workgroup does a counting sort with the counters in LDS:
+//   count (LDS atomics) -> exclusive scan = rowptr -> placement in chunks of 1024 positions, in order.
+// Stable without a sort: before a chunk claims its slots every position reads where its destination's run stands (prev);
+// the claims (LDS atomicAdd) hand out the slots [prev, prev + k) of the chunk's k positions with that destination in SOME
+// order; a position's stable slot is prev + (how many of those k are smaller than it), counted by reading the k claimed
+// entries back — k is 1-2 on real graphs, and earlier chunks hold only smaller positions, later ones only larger.
+// `companion` (optional): a second int64 array in position order (the edge list's source row); col[slot] = companion[e]
+// comes out of the same launch, so the CSR column array needs no permute pass.
+constexpr int SMALL_THREADS = 1024;
+constexpr int64_t SMALL_MAX_E = 65536, SMALL_MAX_N = 40000;   // (N + 1) counters of 4 B (+ the scan scratch) in 160 KiB of LDS
+
+__global__ __launch_bounds__(SMALL_THREADS) void plan_small_kernel(const int64_t* __restrict__ index,
+                                                                   const int64_t* __restrict__ companion, int E, int N,
+                                                                   int32_t* __restrict__ rowptr, int32_t* __restrict__ perm,
+                                                                   int64_t* __restrict__ col) {
+    extern __shared__ uint32_t s_cur[];   // [N + 1]
+    __shared__ uint32_t s_tmp[SMALL_THREADS / 64];
+    const int t = threadIdx.x;
+    for (int n = t; n <= N; n += SMALL_THREADS) s_cur[n] = 0u;
+    __syncthreads();
+    for (int e = t; e < E; e += SMALL_THREADS) {
+        const int64_t d = index[e];
+        if (d >= 0 && d < N) atomicAdd(&s_cur[d], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over [0, N]: a contiguous run per thread, block scan of the run sums
+    const int per = (N + 1 + SMALL_THREADS - 1) / SMALL_THREADS;
+    const int lo = min(t * per, N + 1), hi = min(lo + per, N + 1);
+    uint32_t run = 0;
+    for (int n = lo; n < hi; ++n) run += s_cur[n];
+    uint32_t off = block_excl_scan_u32<SMALL_THREADS / 64>(run, s_tmp, nullptr);
+    for (int n = lo; n < hi; ++n) {
+        const uint32_t c = s_cur[n];
+        s_cur[n] = off;
+        rowptr[n] = (int32_t)off;
+        off += c;
+    }
+    __syncthreads();
+    for (int base = 0; base < E; base += SMALL_THREADS) {
+        const int e = base + t;
+        int64_t d = -1, comp = 0;
+        if (e < E) {
+            d = index[e];
+            if (d < 0 || d >= N) d = -1;   // out of range: belongs to no destination (the radix build sorts these past rowptr[N])
+            if (companion) comp = companion[e];
+        }
+        uint32_t prev = 0;
+        if (d >= 0) prev = s_cur[d];
+        __syncthreads();
+        if (d >= 0) perm[atomicAdd(&s_cur[d], 1u)] = e;
+        __syncthreads();                      // the chunk's claims are in `perm` (this workgroup's own writes) and s_cur
+        uint32_t rank = 0;
+        if (d >= 0) {
+            const uint32_t end = s_cur[d];
+            // read at device scope (past this CU's L1: the line may have been cached before a neighbouring slot was claimed)
+            for (uint32_t j = prev; j < end; ++j)
+                rank += (__hip_atomic_load(&perm[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) ? 1u : 0u;
+        }
+        __syncthreads();                      // everyone has read the unordered entries
+        if (d >= 0) {
+            perm[prev + rank] = e;
+            if (col) col[prev + rank] = comp;
+        }
     }
 }
 
@@ -204,6 +276,32 @@ extern "C" int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N, int
         hipLaunchKernelGGL(fill_gaps_kernel, dim3(512), dim3(256), 0, stream, rowptr, gap_list, gap_count);
     }
     return gnnops_check_launch("plan_build");
+}
+
+
+// One-launch plan of a small index (see plan_small_kernel). gnnops_plan_small_fits says whether (E, N) qualify.
+extern "C" int gnnops_plan_small_fits(int64_t E, int64_t N) {
+    const char* sw = getenv("GNNOPS_PLAN_SMALL");   // A/B and tests: 0 = always the radix build
+    if (sw && sw[0] == '0') return 0;
+    return E > 0 && E <= SMALL_MAX_E && N > 0 && N <= SMALL_MAX_N;
+}
+
+extern "C" int gnnops_plan_build_small(const int64_t* index, const int64_t* companion, int64_t E, int64_t N, int32_t* rowptr,
+                                       int32_t* perm, int64_t* col, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(gnnops_plan_small_fits(E, N), GNNOPS_EUNSUPPORTED, "plan_build_small: needs 0 < E <= %lld and 0 < N <= %lld",
+                   (long long)SMALL_MAX_E, (long long)SMALL_MAX_N);
+    GNNOPS_REQUIRE(index && rowptr && perm && (!companion == !col), GNNOPS_EINVAL, "plan_build_small: null pointer");
+    const size_t lds = (size_t)(N + 1) * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((SMALL_MAX_N + 1) * 4)) != hipSuccess)
+            return gnnops_check_launch("plan_build_small attribute");
+        configured = true;
+    }
+    hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(SMALL_THREADS), lds, (hipStream_t)s, index, companion, (int)E, (int)N,
+                       rowptr, perm, col);
+    return gnnops_check_launch("plan_build_small");
 }
 
 // rowptr of an already sorted int64 index (torch_scatter.segment_coo's input contract; also CSR <- sorted COO rows).

@@ -24,6 +24,8 @@ SIGNATURES = {
     "gnnops_index_max": (_ci, [_vp, _i64, _vp, _vp]),
     "gnnops_plan_workspace_bytes": (_sz, [_i64, _i64]),
     "gnnops_plan_build": (_ci, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "gnnops_plan_small_fits": (_ci, [_i64, _i64]),
+    "gnnops_plan_build_small": (_ci, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gnnops_segment_reduce": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp]),
     "gnnops_bucket_workspace_bytes": (_sz, [_i64, _i64]),
     "gnnops_bucket_partition": (_ci, [_vp, _i64, _i64, _vp, _sz, _vp]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "gnnops_segment_composite_hubs": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp, _sz, _vp]),
     "gnnops_addmm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gnnops_addmm": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
+    "gnnops_addmm_ld": (_ci, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
     "gnnops_fused_index_add_select_sum_workspace_bytes": (_sz, [_i64, _i64]),
     "gnnops_fused_index_add_select_sum": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp, _sz, _vp]),
 }

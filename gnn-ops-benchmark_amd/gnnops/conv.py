@@ -75,8 +75,11 @@ def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=
         raise RuntimeError("edge_reduce: out has one row per destination")
     out, ldo = _rows(out, "out", 1, width)
     avg_log, avg_lin = (1.0, 1.0) if avg_deg is None else (float(avg_deg["log"]), float(avg_deg["lin"]))
-    plan = get_plan(dst_rows, num_dst, owner=edge_index, tag=1)
-    col, _ = _csr_arrays(plan, src_rows, None, owner=edge_index, tag=0) if E else (src_rows, None)
+    plan = get_plan(dst_rows, num_dst, owner=edge_index, tag=1, companion=src_rows)   # small graphs: col comes with the plan
+    if plan.col is not None or E == 0:
+        col = plan.col if E else src_rows
+    else:
+        col, _ = _csr_arrays(plan, src_rows, None, owner=edge_index, tag=0)
     c_aggr = (ctypes.c_int * len(aggr_ids))(*aggr_ids)
     c_scal = (ctypes.c_int * max(len(scal_ids), 1))(*scal_ids)
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731

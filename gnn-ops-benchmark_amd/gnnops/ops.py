@@ -92,9 +92,11 @@ class Plan:
     (scatter_*, index_add_, index_select push form) — build it once per static edge_index.
     """
 
-    __slots__ = ("rowptr", "perm", "E", "N", "_csr", "__weakref__")
+    __slots__ = ("rowptr", "perm", "E", "N", "col", "_csr", "__weakref__")
 
-    def __init__(self, index, N):
+    def __init__(self, index, N, companion=None):
+        """``companion`` (optional int64 [E], e.g. the source row of the edge list whose destination row is ``index``): small
+        inputs are planned by ONE launch that also emits ``self.col`` = companion in plan order (None otherwise)."""
         _require_gpu(index)
         _check_index(index, "Plan")
         if index.dim() != 1:
@@ -106,6 +108,17 @@ class Plan:
         dev = index.device
         self.rowptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
         self.perm = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
+        self.col = None
+        if L.gnnops_plan_small_fits(self.E, self.N):   # one workgroup, one launch (csrc/plan.hip plan_small_kernel)
+            if companion is not None:
+                companion = companion.contiguous()
+                self.col = torch.empty(self.E, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.gnnops_plan_build_small(index.data_ptr(), companion.data_ptr() if companion is not None else None, self.E,
+                                               self.N, self.rowptr.data_ptr(), self.perm.data_ptr(),
+                                               self.col.data_ptr() if self.col is not None else None, _stream())
+            check(rc, "plan_build_small")
+            return
         ws_bytes = L.gnnops_plan_workspace_bytes(self.E, self.N)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
@@ -123,6 +136,7 @@ class Plan:
         if state.get("format") != 1:
             raise ValueError("Plan.from_state_dict: unknown format")
         self = object.__new__(cls)
+        self.col = None
         self.E, self.N = int(state["E"]), int(state["N"])
         self.rowptr = state["rowptr"].to(device=device, dtype=torch.int32).contiguous()
         perm = state["perm"].to(device=device, dtype=torch.int32).contiguous()
@@ -164,7 +178,7 @@ def _version_of(t):
     return None if t.is_inference() else t._version
 
 
-def get_plan(index, N, owner=None, tag=0):
+def get_plan(index, N, owner=None, tag=0, companion=None):
     """Plan for ``index`` (cached per tensor object + version counter while the cache is enabled).
 
     ``owner`` (default: ``index`` itself) is the tensor object the cache entry is tied to: a row of a COO
@@ -177,14 +191,14 @@ def get_plan(index, N, owner=None, tag=0):
         return index
     owner = index if owner is None else owner
     if not _plan_cache_enabled or owner.is_inference():
-        return Plan(index, N)
+        return Plan(index, N, companion)
     key = (id(owner), tag)
     hit = _plan_cache.get(key)
     if hit is not None:
         ref, version, n, plan = hit
         if ref() is owner and version == owner._version and n == N:
             return plan
-    plan = Plan(index, N)
+    plan = Plan(index, N, companion)
     if len(_plan_cache) >= _PLAN_CACHE_MAX:
         _plan_cache.pop(next(iter(_plan_cache)))
 
@@ -632,8 +646,12 @@ def addmm(input, mat1, mat2, *, beta=1, alpha=1):
     dt = _DT[mat1.dtype]
     M, K = mat1.shape
     N = mat2.size(1)
+    ld_input = N
     if input is not None:
-        input = input.expand(M, N).contiguous()
+        if input.numel() == N and (input.dim() == 1 or input.size(0) == 1) and M > 1:
+            input, ld_input = input.contiguous(), 0          # one row for every output row (a Linear bias): never expanded
+        else:
+            input = input.expand(M, N).contiguous()
     mat1 = mat1.contiguous()
     mat2 = mat2.contiguous()
     out = torch.empty((M, N), dtype=mat1.dtype, device=mat1.device)
@@ -641,8 +659,8 @@ def addmm(input, mat1, mat2, *, beta=1, alpha=1):
     ws_bytes = L.gnnops_addmm_workspace_bytes(M, N, K)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat1.device) if ws_bytes else None
     with torch.cuda.device(mat1.device):
-        rc = L.gnnops_addmm(input.data_ptr() if input is not None else None, mat1.data_ptr(), mat2.data_ptr(),
-                            out.data_ptr(), M, N, K, dt, ws.data_ptr() if ws is not None else None, ws_bytes, _stream())
+        rc = L.gnnops_addmm_ld(input.data_ptr() if input is not None else None, ld_input, mat1.data_ptr(), mat2.data_ptr(),
+                               out.data_ptr(), M, N, K, dt, ws.data_ptr() if ws is not None else None, ws_bytes, _stream())
     check(rc, "addmm")
     return out
 

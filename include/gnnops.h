@@ -76,6 +76,12 @@ size_t gnnops_plan_workspace_bytes(int64_t E, int64_t N);
 int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N,
                       int32_t* rowptr, int32_t* perm,
                       void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+/* The same plan in ONE launch for small inputs (gnnops_plan_small_fits(E, N) != 0: E <= 65536 positions, N <= 40000
+ * destinations — a batch of small graphs, app_bm/benchmark_convs.py): one workgroup, counters in LDS, stable. `companion`
+ * (optional, int64 [E], e.g. the edge list's source row) comes back in plan order as col [E] from the same launch. */
+int gnnops_plan_small_fits(int64_t E, int64_t N);
+int gnnops_plan_build_small(const int64_t* index, const int64_t* companion, int64_t E, int64_t N, int32_t* rowptr,
+                            int32_t* perm, int64_t* col, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Segment reduce over a plan — the kernel behind, with layout R:
@@ -285,6 +291,10 @@ size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* 0 whe
 int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out,
                  int64_t M, int64_t N, int64_t K, int dtype,
                  void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+/* The same with a row pitch for `input` (elements): ld_input = N is gnnops_addmm; ld_input = 0 adds ONE row [N] to every
+ * output row — the bias of a Linear layer (app_bm/groq_script.py:75-76 lin_f / lin_s) without materialising [M, N]. */
+int gnnops_addmm_ld(const void* input, int64_t ld_input, const void* mat1, const void* mat2, void* out, int64_t M,
+                    int64_t N, int64_t K, int dtype, void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused index_select(index_add(input, dim, index, other), dim, index).sum(dim)

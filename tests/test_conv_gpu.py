@@ -160,6 +160,29 @@ def test_edge_reduce_refuses_bad_arguments(conv):
         conv.edge_reduce("copy", xg, ei, 10)
 
 
+@pytest.mark.parametrize("E,N", [(1, 1), (40, 21), (1023, 7), (1024, 1024), (1025, 40000), (18744, 9134), (65536, 300), (65536, 40000)])
+def test_one_launch_plan_equals_the_radix_plan(E, N, monkeypatch):
+    """csrc/plan.hip plan_small_kernel (one workgroup, counters in LDS) against the radix build: rowptr, perm (stable:
+    ascending positions inside every destination) and the companion column, bit for bit; a hub destination included."""
+    import gnnops
+
+    g = torch.Generator().manual_seed(E + N)
+    idx = torch.randint(0, N, (E,), generator=g)
+    if E > 100:
+        idx[torch.randint(0, E, (E // 3,), generator=g)] = N // 2        # a hub: a third of all positions
+    comp = torch.randint(0, 1 << 40, (E,), generator=g)
+    small = gnnops.Plan(idx.cuda(), N, comp.cuda())
+    assert small.col is not None, "the one-launch build did not run"
+    monkeypatch.setenv("GNNOPS_PLAN_SMALL", "0")
+    radix = gnnops.Plan(idx.cuda(), N, comp.cuda())
+    assert radix.col is None
+    assert torch.equal(small.rowptr, radix.rowptr)
+    assert torch.equal(small.perm[:E], radix.perm[:E])
+    assert torch.equal(small.col.cpu(), comp[radix.perm[:E].long().cpu()])
+    order = torch.sort(idx, stable=True).indices
+    assert torch.equal(small.perm[:E].cpu().long(), order)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the layers
 # ---------------------------------------------------------------------------------------------------------------------

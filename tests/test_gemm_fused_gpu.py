@@ -257,3 +257,40 @@ def test_addmm_rows_and_columns_do_not_leak(gnnops, M, N, K):
     ref = Ac @ Bc
     bound = 2.0 ** -10 * ref.abs() + 4 * K * 2.0 ** -24 * (Ac.abs() @ Bc.abs()) + 1e-30
     assert bool(((clean - ref).abs() <= bound).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(9134, 44, 11), (75, 2, 1), (600, 2048, 13), (6177, 2048, 178), (29, 11, 22), (131, 77, 9),
+                                   (4096, 4096, 64), (3000, 3100, 264), (700, 900, 257), (8192, 2048, 128)])
+def test_addmm_bias_row_and_odd_rows(gnnops, M, N, K, dtype):
+    """What a Linear layer needs (gnnops/conv.py): the bias is ONE row added to every output row (gnnops_addmm_ld, pitch 0 —
+    never expanded to [M, N]) and operand rows of any length go to the register-staged kernel as they are (K = 11 node
+    features, N = 44: element / 4-B / 8-B pieces instead of padded copies). Every kernel of the family takes the pitch:
+    shapes cover the register-staged, the 128 x 128 and the 256 x 256 LDS-DMA kernels and both fp32 kernels."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(dtype)
+    B = (torch.rand(K, N, generator=g) * 2 - 1 + torch.arange(N).float().view(1, N) / N).to(dtype)
+    bias = (torch.rand(N, generator=g) * 2 - 1).to(dtype)
+    eps = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8, torch.float32: 2.0 ** -24}[dtype]
+    ref = bias.double().view(1, N) + A.double() @ B.double()
+    bound = eps * ref.abs() + 4 * K * 2.0 ** -24 * (A.double().abs() @ B.double().abs()) + eps * bias.double().abs().view(1, N) + 1e-30
+    for b in (bias, bias.view(1, N)):
+        got = gnnops.addmm(b.cuda(), A.cuda(), B.cuda()).cpu().double()
+        assert got.shape == (M, N)
+        assert bool(((got - ref).abs() <= bound).all()), f"max err/bound {((got - ref).abs() / bound).max().item()}"
+
+
+def test_addmm_more_rows_than_one_grid(gnnops):
+    """M = 8.4M rows (a node-feature matrix of BASELINE config 2's order): more 128-row tiles than gridDim.y holds — run as
+    slabs. Checked on sampled rows against float64."""
+    M, K, N = 65280 * 128 + 777, 16, 24
+    g = torch.Generator(device="cuda").manual_seed(4)
+    A = (torch.rand(M, K, generator=g, device="cuda") - 0.5).half()
+    B = (torch.rand(K, N, generator=g, device="cuda") - 0.5).half()
+    bias = torch.rand(N, generator=g, device="cuda").half()
+    got = gnnops.addmm(bias, A, B)
+    rows = torch.tensor([0, 1, 127, 128, 65280 * 128 - 1, 65280 * 128, 65280 * 128 + 1, M - 1, 4_000_003], device="cuda")
+    ref = bias.double().view(1, N) + A[rows].double() @ B.double()
+    assert torch.allclose(got[rows].double(), ref, rtol=2e-3, atol=2e-3)
+    full = gnnops.addmm(bias.expand(M, N).contiguous(), A, B)
+    assert torch.equal(full, got)
