@@ -21,6 +21,7 @@
 // each output row stored once, messages live in registers, fp32 arithmetic, ONE rounding on store. Algorithmic bytes per
 // launch: E * (q row + 8 B column id (+ w row)) + N * (p row + out row) + 4 (N + 1).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -37,6 +38,7 @@ struct Args {
     int n_aggr, aggr[5], n_scal, scal[5];
     float avg_log, avg_lin;
     int gshift, kchunks;
+    int nt;   // gathered table does not fit the Infinity Cache: stream it past (nontemporal 16-B loads)
 };
 
 template <int F> struct Parts;   // K-wide parts per row of q / p / w
@@ -45,48 +47,76 @@ template <> struct Parts<F_ADD> { static constexpr int Q = 1, P = 1, W = 1; };
 template <> struct Parts<F_CGCONV> { static constexpr int Q = 2, P = 2, W = 2; };
 template <> struct Parts<F_FILM> { static constexpr int Q = 1, P = 2, W = 0; };
 
-template <typename T, int VEC, bool NT>
-__device__ inline void load_vec(const T* p, float* f) {
-    if constexpr (VEC == 1) {
-        f[0] = Elem<T>::load(p);
+// VEC consecutive elements of a row as one access of VEC * sizeof(T) bytes (16, 8, 4 or the element itself). Loading and
+// unpacking are separate so that a step's loads can all be issued before the first conversion waits for one of them.
+template <typename T, int VEC>
+__device__ inline u32x4 load_raw(const T* p, bool nt = false) {
+    constexpr int BYTES = VEC * (int)sizeof(T);
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if constexpr (BYTES == 16) {
+        r = nt ? load16<true>(p) : load16<false>(p);
+    } else if constexpr (BYTES == 8) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        r.x = t.x; r.y = t.y;
+    } else if constexpr (BYTES == 4) {
+        r.x = *reinterpret_cast<const uint32_t*>(p);
     } else {
-        Elem<T>::unpack(load16<NT>(p), f);
+        r.x = *reinterpret_cast<const uint16_t*>(p);
     }
+    return r;
 }
 template <typename T, int VEC>
+__device__ inline void unpack_vec(const u32x4& r, float* f) {
+    float g[Elem<T>::VEC];
+    Elem<T>::unpack(r, g);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) f[v] = g[v];
+}
+template <typename T, int VEC>
+__device__ inline void load_vec(const T* p, float* f, bool nt = false) { unpack_vec<T, VEC>(load_raw<T, VEC>(p, nt), f); }
+template <typename T, int VEC>
 __device__ inline void store_vec(T* p, const float* f) {
+    constexpr int BYTES = VEC * (int)sizeof(T);
     if constexpr (VEC == 1) {
         Elem<T>::store(p, f[0]);
     } else {
-        store16<true>(p, Elem<T>::pack(f));
+        float g[Elem<T>::VEC];
+#pragma unroll
+        for (int v = 0; v < Elem<T>::VEC; ++v) g[v] = v < VEC ? f[v] : 0.f;
+        const u32x4 r = Elem<T>::pack(g);
+        if constexpr (BYTES == 16) store16<true>(p, r);
+        else if constexpr (BYTES == 8) *reinterpret_cast<uint2*>(p) = uint2{r.x, r.y};
+        else *reinterpret_cast<uint32_t*>(p) = r.x;
     }
 }
 
-__device__ inline float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
-// torch.nn.functional.softplus (beta 1, threshold 20): x above the threshold, log1p(exp(x)) below
+// Straight-line fp32 forms (no per-element branch, no IEEE division sequence: at 5 edges x 128 columns per row the edge loop
+// is otherwise VALU-bound — 2353 vector instructions and 191 branches per 32 messages before, see profiles/round2_f_*):
+// one v_exp + one v_rcp for the sigmoid; one v_exp + one v_log for the softplus.
+__device__ inline float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+// softplus(x) = max(x, 0) + log1p(exp(-|x|)). torch's form (beta 1, threshold 20: x itself above 20) is the same number in
+// fp32: above 20 the log1p term is < 2.1e-9, below half an ulp of x. log1p by its series where 1 + t would round t away;
+// elsewhere 1 + t is in [1, 2], so the bare v_log_f32 needs none of logf's range handling.
 __device__ inline float softplus_f(float x) {
-    if (x > 20.f) return x;
-    const float t = __expf(-fabsf(x));
-    const float l = t < 1e-3f ? t * (1.f - t * (0.5f - t * (1.f / 3.f))) : __logf(1.f + t);
-    return fmaxf(x, 0.f) + l;
+    const float t = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504f);
+    const float series = t * (1.f - t * (0.5f - t * (1.f / 3.f)));
+    const float lg = __builtin_amdgcn_logf(1.f + t) * 0.693147181f;
+    return fmaxf(x, 0.f) + (t < 1e-3f ? series : lg);
 }
 
-template <int F, int VEC>
-__device__ inline void message(const float (*pv)[VEC], const float (*qv)[VEC], const float (*wv)[VEC], bool has_p, bool has_w,
-                               float* m) {
+template <int F, bool HAS_W, int VEC>
+__device__ inline void message(const float (*pv)[VEC], const float (*qv)[VEC], const float (*wv)[VEC], float* m) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         if constexpr (F == F_COPY) {
             m[v] = qv[0][v];
         } else if constexpr (F == F_ADD) {
-            float t = qv[0][v];
-            if (has_p) t = pv[0][v] + t;
-            if (has_w) t = t + wv[0][v];
+            float t = pv[0][v] + qv[0][v];
+            if constexpr (HAS_W) t = t + wv[0][v];
             m[v] = t;
         } else if constexpr (F == F_CGCONV) {
-            float f = qv[0][v], s = qv[1][v];
-            if (has_p) { f = pv[0][v] + f; s = pv[1][v] + s; }
-            if (has_w) { f = f + wv[0][v]; s = s + wv[1][v]; }
+            float f = pv[0][v] + qv[0][v], s = pv[1][v] + qv[1][v];
+            if constexpr (HAS_W) { f = f + wv[0][v]; s = s + wv[1][v]; }
             m[v] = sigmoid_f(f) * softplus_f(s);
         } else {   // F_FILM: beta = part 0, gamma = part 1
             m[v] = fmaxf(pv[1][v] * qv[0][v] + pv[0][v], 0.f);
@@ -95,67 +125,89 @@ __device__ inline void message(const float (*pv)[VEC], const float (*qv)[VEC], c
 }
 
 // MULTI = false: one running sum (sum or mean only); true: sum, sum of squares, min and max together.
-template <typename T, int F, bool MULTI, int VEC, bool NT>
+// Lanes per row: a message that costs real arithmetic (CGCONV: two exp, a log and a reciprocal per element; the four
+// accumulators of MULTI) is spread over as many lanes as the row has 4-byte pieces — up to the whole wave on ONE row — so
+// that rows of different degree do not share a wave: with 16-B lanes four rows of K = 128 fp16 share one, the wave runs
+// for its longest row (~7.7 edges at a mean of 5) and half the issued messages are masked off. Plain copies / adds keep
+// the 16-B lanes (fewest memory instructions; they are bandwidth-bound).
+template <typename T, int F, bool MULTI, bool HAS_W, int VEC, bool WAVE_ROW>
 __global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
     constexpr int U = Parts<F>::Q == 2 ? 4 : 8;
     constexpr int NQ = Parts<F>::Q, NP = Parts<F>::P > 0 ? Parts<F>::P : 1, NW = Parts<F>::W > 0 ? Parts<F>::W : 1;
-    const T* q = (const T*)a.q;
-    const T* p = (const T*)a.p;
-    const T* w = (const T*)a.w;
-    const T* add = (const T*)a.add;
-    T* out = (T*)a.out;
-    const bool has_p = Parts<F>::P > 0 && p != nullptr, has_w = Parts<F>::W > 0 && w != nullptr;
+    const T* __restrict__ q = (const T*)a.q;
+    const T* __restrict__ p = (const T*)a.p;
+    const T* __restrict__ w = (const T*)a.w;
+    const T* __restrict__ add = (const T*)a.add;
+    const int32_t* __restrict__ rowptr = a.rowptr;
+    const int32_t* __restrict__ perm = a.perm;
+    const int64_t* __restrict__ col = a.col;
+    T* __restrict__ out = (T*)a.out;
     const int G = 1 << a.gshift;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> a.gshift;
     const int gl = (int)(gtid & (G - 1));
     const int64_t items = (int64_t)a.kchunks * a.N;
-    const int64_t K = a.K;
+    const int K = (int)a.K, ldq = (int)a.ldq, ldw = (int)a.ldw;   // < 2^31 (host-checked): row offsets are one 32 x 32 -> 64 multiply
 
     for (int64_t item = gtid >> a.gshift; item < items; item += ngroups) {
-        const int64_t n = item % a.N;
-        const int chunk = (int)(item / a.N);
-        const int64_t c0 = ((int64_t)chunk * G + gl) * VEC;
+        int n, chunk;
+        if (a.kchunks == 1) { n = (int)item; chunk = 0; } else { n = (int)(item % a.N); chunk = (int)(item / a.N); }
+        if constexpr (WAVE_ROW) {   // the whole wave is on this row: row bounds, edge ids and the loop itself are scalar
+            n = __builtin_amdgcn_readfirstlane(n);
+            chunk = __builtin_amdgcn_readfirstlane(chunk);
+        }
+        const int c0 = (chunk * G + gl) * VEC;
         if (c0 >= K) continue;
-        const int32_t beg = a.rowptr[n], end = a.rowptr[n + 1];
+        int32_t beg = rowptr[n], end = rowptr[n + 1];
+        if constexpr (WAVE_ROW) {
+            beg = __builtin_amdgcn_readfirstlane(beg);
+            end = __builtin_amdgcn_readfirstlane(end);
+        }
 
         float pv[NP][VEC];
-        if (has_p) {
+        if constexpr (Parts<F>::P > 0) {
 #pragma unroll
-            for (int r = 0; r < NP; ++r) load_vec<T, VEC, false>(p + n * a.ldp + r * K + c0, pv[r]);
+            for (int r = 0; r < NP; ++r) load_vec<T, VEC>(p + (int64_t)n * a.ldp + r * K + c0, pv[r]);
         }
         float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) { sum[v] = 0.f; sq[v] = 0.f; mn[v] = __builtin_huge_valf(); mx[v] = -__builtin_huge_valf(); }
 
         for (int32_t j = beg; j < end; j += U) {
-            int64_t c[U];
-            int32_t e[U];
-            float qv[U][NQ][VEC], wv[U][NW][VEC];
+            int c[U], e[U];
+            u32x4 qr[U][NQ], wr[U][NW];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                c[u] = -1;
+            for (int u = 0; u < U; ++u) {       // all the step's edge ids first ...
+                c[u] = 0;
+                e[u] = 0;
                 if (j + u < end) {
-                    c[u] = a.col[j + u];
-                    e[u] = a.perm ? a.perm[j + u] : j + u;
+                    c[u] = (int)col[j + u];
+                    if constexpr (HAS_W) e[u] = perm ? perm[j + u] : j + u;
+                    if constexpr (WAVE_ROW) { c[u] = __builtin_amdgcn_readfirstlane(c[u]); e[u] = __builtin_amdgcn_readfirstlane(e[u]); }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (c[u] >= 0) {
+            for (int u = 0; u < U; ++u) {       // ... then all its row loads in flight together (raw words: no conversion here)
+                if (j + u < end) {
 #pragma unroll
-                    for (int r = 0; r < NQ; ++r) load_vec<T, VEC, NT>(q + c[u] * a.ldq + r * K + c0, qv[u][r]);
-                    if (has_w) {
+                    for (int r = 0; r < NQ; ++r) qr[u][r] = load_raw<T, VEC>(q + (int64_t)c[u] * ldq + r * K + c0, a.nt != 0);
+                    if constexpr (HAS_W) {
 #pragma unroll
-                        for (int r = 0; r < NW; ++r) load_vec<T, VEC, true>(w + (int64_t)e[u] * a.ldw + r * K + c0, wv[u][r]);
+                        for (int r = 0; r < NW; ++r) wr[u][r] = load_raw<T, VEC>(w + (int64_t)e[u] * ldw + r * K + c0, true);
                     }
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (c[u] >= 0) {
-                    float m[VEC];
-                    message<F, VEC>(pv, qv[u], wv[u], has_p, has_w, m);
+                if (j + u < end) {   // skipped outright once every row of the wave is past its end
+                    float qv[NQ][VEC], wv[NW][VEC], m[VEC];
+#pragma unroll
+                    for (int r = 0; r < NQ; ++r) unpack_vec<T, VEC>(qr[u][r], qv[r]);
+                    if constexpr (HAS_W) {
+#pragma unroll
+                        for (int r = 0; r < NW; ++r) unpack_vec<T, VEC>(wr[u][r], wv[r]);
+                    }
+                    message<F, HAS_W, VEC>(pv, qv, wv, m);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         sum[v] += m[v];
@@ -172,7 +224,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
         const int32_t cnt = end - beg;
         const float degc = (float)(cnt < 1 ? 1 : cnt);
         const float logd = __logf(degc + 1.f);
-        T* orow = out + n * a.ldo + c0;
+        T* orow = out + (int64_t)n * a.ldo + c0;
         for (int s = 0; s < a.n_scal; ++s) {
             float scale = 1.f;
             switch (a.scal[s]) {
@@ -201,46 +253,62 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
                 }
                 if (add && s == 0 && g == 0) {
                     float t[VEC];
-                    load_vec<T, VEC, false>(add + n * a.ldadd + c0, t);
+                    load_vec<T, VEC>(add + (int64_t)n * a.ldadd + c0, t);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o[v] += t[v];
                 }
-                store_vec<T, VEC>(orow + ((int64_t)s * a.n_aggr + g) * K, o);
+                store_vec<T, VEC>(orow + (int64_t)(s * a.n_aggr + g) * K, o);
             }
         }
     }
 }
 
-template <typename T, int F, bool MULTI>
-int launch(const Args& a0, bool vec_ok, hipStream_t stream) {
-    Args a = a0;
-    constexpr int VEC = Elem<T>::VEC;
+template <typename T, int F, bool MULTI, bool HAS_W, int VEC>
+int launch_vec(Args& a, hipStream_t stream) {
     // gathered tables beyond ~2 GiB do not stay in the Infinity Cache between visits: stream them past it (as spmm.hip)
-    const bool nt = (double)a.N * (double)a.ldq * sizeof(T) > 2.0 * 1024 * 1024 * 1024;
-    const int64_t lanes = vec_ok ? a.K / VEC : a.K;
+    a.nt = (double)a.N * (double)a.ldq * sizeof(T) > 2.0 * 1024 * 1024 * 1024;
+    const int64_t lanes = a.K / VEC;
     int gshift = 0;
     while ((1 << gshift) < lanes && gshift < 6) ++gshift;
     a.gshift = gshift;
     a.kchunks = (int)gnnops_cdiv(lanes, (int64_t)1 << gshift);
     const int64_t items = (int64_t)a.kchunks * a.N;
     const int grid = gnnops_grid_cap(gnnops_cdiv(items, 256 >> gshift), 256 * 64);
-    if (vec_ok) {
-        if (nt) hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, VEC, true>), dim3(grid), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, VEC, false>), dim3(grid), dim3(256), 0, stream, a);
-    } else {
-        hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, 1, false>), dim3(grid), dim3(256), 0, stream, a);
-    }
+    if (gshift == 6) hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, HAS_W, VEC, true>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, HAS_W, VEC, false>), dim3(grid), dim3(256), 0, stream, a);
     return gnnops_check_launch("edge_reduce");
 }
 
+template <typename T, int F, bool MULTI, bool HAS_W>
+int launch(const Args& a0, int max_vec, hipStream_t stream) {
+    Args a = a0;
+    constexpr int NATIVE = Elem<T>::VEC;
+    constexpr bool HEAVY = F == F_CGCONV || MULTI;
+    // widest piece the operands allow (max_vec: alignment of every pointer / pitch, in elements), narrowed for HEAVY
+    // messages until the row fills the wave
+    int vec = NATIVE;
+    while (vec > 1 && (vec > max_vec || a.K % vec != 0)) vec >>= 1;
+    if (HEAVY)
+        while (vec > 1 && vec * sizeof(T) > 4 && a.K / vec < 64) vec >>= 1;
+    const char* sw = getenv("GNNOPS_EDGE_VEC");   // A/B (tools/time_edge_reduce.py): force the piece width in elements
+    if (sw) { int f = atoi(sw); if (f >= 1 && f <= vec && (f & (f - 1)) == 0) vec = f; }
+    if constexpr (NATIVE == 8) {
+        if (vec == 8) return launch_vec<T, F, MULTI, HAS_W, 8>(a, stream);
+    }
+    if (vec == 4) return launch_vec<T, F, MULTI, HAS_W, 4>(a, stream);
+    if (vec == 2) return launch_vec<T, F, MULTI, HAS_W, 2>(a, stream);
+    return launch_vec<T, F, MULTI, HAS_W, 1>(a, stream);
+}
+
 template <typename T>
-int dispatch(int functor, bool multi, const Args& a, bool vec_ok, hipStream_t stream) {
-#define GNNOPS_ER(F) return multi ? launch<T, F, true>(a, vec_ok, stream) : launch<T, F, false>(a, vec_ok, stream)
+int dispatch(int functor, bool multi, const Args& a, int max_vec, hipStream_t stream) {
+#define GNNOPS_ER(F, W) return multi ? launch<T, F, true, W>(a, max_vec, stream) : launch<T, F, false, W>(a, max_vec, stream)
+    const bool has_w = a.w != nullptr;
     switch (functor) {
-        case F_COPY: GNNOPS_ER(F_COPY);
-        case F_ADD: GNNOPS_ER(F_ADD);
-        case F_CGCONV: GNNOPS_ER(F_CGCONV);
-        case F_FILM: GNNOPS_ER(F_FILM);
+        case F_COPY: GNNOPS_ER(F_COPY, false);
+        case F_ADD: if (has_w) GNNOPS_ER(F_ADD, true); else GNNOPS_ER(F_ADD, false);
+        case F_CGCONV: if (has_w) GNNOPS_ER(F_CGCONV, true); else GNNOPS_ER(F_CGCONV, false);
+        case F_FILM: GNNOPS_ER(F_FILM, false);
     }
 #undef GNNOPS_ER
     gnnops_set_error("edge_reduce: unknown functor %d", functor);
@@ -256,12 +324,15 @@ extern "C" int gnnops_edge_reduce(int functor, const void* q, int64_t ldq, const
                                   gnnops_stream_t s) {
     GNNOPS_REQUIRE(N >= 0 && E >= 0 && K >= 0, GNNOPS_EINVAL, "edge_reduce: negative size");
     GNNOPS_REQUIRE(N < ((int64_t)1 << 31) && E < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED, "edge_reduce: N and E must be < 2^31");
+    GNNOPS_REQUIRE(K < ((int64_t)1 << 24) && ldq < ((int64_t)1 << 31) && ldw < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED,
+                   "edge_reduce: rows of 2^24 or more elements");
     GNNOPS_REQUIRE(functor >= F_COPY && functor <= F_FILM, GNNOPS_EINVAL, "edge_reduce: unknown functor %d", functor);
     GNNOPS_REQUIRE(n_aggr >= 1 && n_aggr <= 5 && aggr, GNNOPS_EINVAL, "edge_reduce: 1..5 aggregators");
     GNNOPS_REQUIRE(n_scalers >= 0 && n_scalers <= 5 && (n_scalers == 0 || scalers), GNNOPS_EINVAL, "edge_reduce: 0..5 scalers");
     if (N * K == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(rowptr && out && (E == 0 || (q && col)), GNNOPS_EINVAL, "edge_reduce: null pointer");
-    GNNOPS_REQUIRE(functor != F_FILM || p, GNNOPS_EINVAL, "edge_reduce: the FiLM message needs p = [beta | gamma]");
+    GNNOPS_REQUIRE(functor == F_COPY || p, GNNOPS_EINVAL, "edge_reduce: this message needs the per-destination rows p");
+    if (functor == F_COPY || functor == F_FILM) w = nullptr;   // these messages have no per-edge term
     Args a{};
     a.q = q; a.p = p; a.w = w; a.add = add; a.rowptr = rowptr; a.perm = perm; a.col = col; a.out = out;
     a.N = N; a.K = K; a.ldq = ldq; a.ldp = ldp; a.ldw = ldw; a.ldadd = ldadd; a.ldo = ldo;
@@ -292,12 +363,19 @@ extern "C" int gnnops_edge_reduce(int functor, const void* q, int64_t ldq, const
         case GNNOPS_F16: case GNNOPS_BF16: es = 2; vec = 8; break;
         default: gnnops_set_error("edge_reduce: unknown dtype %d", dtype); return GNNOPS_EINVAL;
     }
-    auto ok16 = [&](const void* ptr, int64_t ld) { return !ptr || ((uintptr_t)ptr % 16 == 0 && (ld * es) % 16 == 0); };
-    const bool vec_ok = K % vec == 0 && ok16(q, ldq) && ok16(p, ldp) && ok16(w, ldw) && ok16(add, ldadd) && ok16(out, ldo);
+    // widest aligned piece (elements) every operand row allows: pointers and pitches in bytes share a power-of-two factor
+    int max_vec = vec;
+    auto narrow = [&](const void* ptr, int64_t ld) {
+        if (!ptr) return;
+        while (max_vec > 1 && ((uintptr_t)ptr % (max_vec * es) != 0 || (ld * es) % (max_vec * es) != 0)) max_vec >>= 1;
+    };
+    narrow(q, ldq); narrow(p, ldp); narrow(w, ldw); narrow(add, ldadd); narrow(out, ldo);
+    if ((K * es) % (max_vec * es) != 0)
+        while (max_vec > 1 && K % max_vec != 0) max_vec >>= 1;
     hipStream_t stream = (hipStream_t)s;
     switch (dtype) {
-        case GNNOPS_F32: return dispatch<float>(functor, multi, a, vec_ok, stream);
-        case GNNOPS_F16: return dispatch<__half>(functor, multi, a, vec_ok, stream);
-        default: return dispatch<__hip_bfloat16>(functor, multi, a, vec_ok, stream);
+        case GNNOPS_F32: return dispatch<float>(functor, multi, a, max_vec, stream);
+        case GNNOPS_F16: return dispatch<__half>(functor, multi, a, max_vec, stream);
+        default: return dispatch<__hip_bfloat16>(functor, multi, a, max_vec, stream);
     }
 }

@@ -122,7 +122,7 @@ __global__ void fill_gaps_kernel(int32_t* __restrict__ rowptr, const int32_t* __
 // `companion` (optional): a second int64 array in position order (the edge list's source row); col[slot] = companion[e]
 // comes out of the same launch, so the CSR column array needs no permute pass.
 constexpr int SMALL_THREADS = 1024;
-constexpr int64_t SMALL_MAX_E = 65536, SMALL_MAX_N = 40000;   // (N + 1) counters of 4 B (+ the scan scratch) in 160 KiB of LDS
+constexpr int64_t SMALL_MAX_E = 12288, SMALL_MAX_N = 40000;   // (N + 1) counters of 4 B (+ the scan scratch) in 160 KiB of LDS
 
 __global__ __launch_bounds__(SMALL_THREADS) void plan_small_kernel(const int64_t* __restrict__ index,
                                                                    const int64_t* __restrict__ companion, int E, int N,
@@ -151,19 +151,25 @@ __global__ __launch_bounds__(SMALL_THREADS) void plan_small_kernel(const int64_t
         off += c;
     }
     __syncthreads();
-    for (int base = 0; base < E; base += SMALL_THREADS) {
-        const int e = base + t;
-        int64_t d = -1, comp = 0;
+    // per chunk of 1024 positions, two barriers:  [claim c]  |  [rank c, read where chunk c+1 starts]  |  [place c, claim c+1] ...
+    auto fetch = [&](int e, int64_t& d, int64_t& comp) {
+        d = -1; comp = 0;
         if (e < E) {
             d = index[e];
             if (d < 0 || d >= N) d = -1;   // out of range: belongs to no destination (the radix build sorts these past rowptr[N])
             if (companion) comp = companion[e];
         }
-        uint32_t prev = 0;
-        if (d >= 0) prev = s_cur[d];
-        __syncthreads();
-        if (d >= 0) perm[atomicAdd(&s_cur[d], 1u)] = e;
-        __syncthreads();                      // the chunk's claims are in `perm` (this workgroup's own writes) and s_cur
+    };
+    int64_t d, comp, d_next = -1, comp_next = 0;
+    fetch(t, d, comp);
+    uint32_t prev = d >= 0 ? s_cur[d] : 0u;
+    __syncthreads();
+    for (int base = 0; base < E; base += SMALL_THREADS) {
+        const int e = base + t;
+        if (d >= 0) perm[atomicAdd(&s_cur[d], 1u)] = e;                  // claim: slots [prev, prev + k) in some order
+        const bool more = base + SMALL_THREADS < E;
+        if (more) fetch(e + SMALL_THREADS, d_next, comp_next);          // the next chunk's keys travel under this chunk's barriers
+        __syncthreads();                                                 // the chunk's claims are in `perm` and in s_cur
         uint32_t rank = 0;
         if (d >= 0) {
             const uint32_t end = s_cur[d];
@@ -171,11 +177,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void plan_small_kernel(const int64_t
             for (uint32_t j = prev; j < end; ++j)
                 rank += (__hip_atomic_load(&perm[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) ? 1u : 0u;
         }
-        __syncthreads();                      // everyone has read the unordered entries
+        const uint32_t prev_next = (more && d_next >= 0) ? s_cur[d_next] : 0u;   // s_cur is final for this chunk
+        __syncthreads();                                                 // everyone has read the unordered entries and s_cur
         if (d >= 0) {
             perm[prev + rank] = e;
             if (col) col[prev + rank] = comp;
         }
+        d = d_next; comp = comp_next; prev = prev_next;
     }
 }
 

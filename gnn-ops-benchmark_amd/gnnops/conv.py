@@ -55,8 +55,8 @@ def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=
     for t in (p, w, add, out):
         if t is not None and t.dtype != q.dtype:
             raise RuntimeError("edge_reduce: operands must have the same dtype")
-    if functor == "film" and p is None:
-        raise RuntimeError("edge_reduce: the FiLM message needs p = [beta | gamma]")
+    if functor != "copy" and p is None:
+        raise RuntimeError(f"edge_reduce: the {functor} message needs the per-destination rows p")
     q, ldq = _rows(q, "q", nq, K)
     p, ldp = _rows(p, "p", np_, K)
     w, ldw = _rows(w, "w", nw, K)

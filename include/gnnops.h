@@ -76,7 +76,7 @@ size_t gnnops_plan_workspace_bytes(int64_t E, int64_t N);
 int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N,
                       int32_t* rowptr, int32_t* perm,
                       void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
-/* The same plan in ONE launch for small inputs (gnnops_plan_small_fits(E, N) != 0: E <= 65536 positions, N <= 40000
+/* The same plan in ONE launch for small inputs (gnnops_plan_small_fits(E, N) != 0: E <= 12288 positions, N <= 40000
  * destinations — a batch of small graphs, app_bm/benchmark_convs.py): one workgroup, counters in LDS, stable. `companion`
  * (optional, int64 [E], e.g. the edge list's source row) comes back in plan order as col [E] from the same launch. */
 int gnnops_plan_small_fits(int64_t E, int64_t N);
@@ -372,8 +372,8 @@ int gnnops_segment_composite_hubs(const void* src, const int32_t* rowptr, const 
  * Edges in destination-sorted (plan) order: rowptr int32 [N+1]; col int64 [E] = source row j of sorted edge position;
  * perm int32 [E] = original edge id of that position (only read when w is given; NULL = identity).
  * functor 0 COPY    f = q                                             rows: q [K]
- *         1 ADD     f = p + q + w   (p, w optional)                         q, p, w [K]
- *         2 CGCONV  f = sigmoid(p_f + q_f + w_f) * softplus(p_s + q_s + w_s) q, p, w [f part K | s part K]; p, w optional
+ *         1 ADD     f = p + q + w   (w optional)                            q, p, w [K]
+ *         2 CGCONV  f = sigmoid(p_f + q_f + w_f) * softplus(p_s + q_s + w_s) q, p, w [f part K | s part K]; w optional
  *         3 FILM    f = relu(gamma * q + beta)                               q [K], p [beta K | gamma K]
  * aggr[]: 0 sum, 1 mean (divide by max(deg, 1)), 2 min, 3 max (0 for rows without edges), 4 std =
  *   sqrt(relu(mean(f^2) - mean(f)^2) + 1e-5) — PNAConv.aggregate; scalers[] (n_scalers == 0: none): 0 identity,
