@@ -122,7 +122,7 @@ __global__ void fill_gaps_kernel(int32_t* __restrict__ rowptr, const int32_t* __
 // `companion` (optional): a second int64 array in position order (the edge list's source row); col[slot] = companion[e]
 // comes out of the same launch, so the CSR column array needs no permute pass.
 constexpr int SMALL_THREADS = 1024;
-constexpr int64_t SMALL_MAX_E = 12288, SMALL_MAX_N = 40000;   // (N + 1) counters of 4 B (+ the scan scratch) in 160 KiB of LDS
+constexpr int64_t SMALL_MAX_E = 24576, SMALL_MAX_N = 40000;   // (N + 1) counters of 4 B (+ the scan scratch) in 160 KiB of LDS
 
 __global__ __launch_bounds__(SMALL_THREADS) void plan_small_kernel(const int64_t* __restrict__ index,
                                                                    const int64_t* __restrict__ companion, int E, int N,

@@ -76,7 +76,7 @@ size_t gnnops_plan_workspace_bytes(int64_t E, int64_t N);
 int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N,
                       int32_t* rowptr, int32_t* perm,
                       void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
-/* The same plan in ONE launch for small inputs (gnnops_plan_small_fits(E, N) != 0: E <= 12288 positions, N <= 40000
+/* The same plan in ONE launch for small inputs (gnnops_plan_small_fits(E, N) != 0: E <= 24576 positions, N <= 40000
  * destinations — a batch of small graphs, app_bm/benchmark_convs.py): one workgroup, counters in LDS, stable. `companion`
  * (optional, int64 [E], e.g. the edge list's source row) comes back in plan order as col [E] from the same launch. */
 int gnnops_plan_small_fits(int64_t E, int64_t N);

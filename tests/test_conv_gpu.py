@@ -160,7 +160,7 @@ def test_edge_reduce_refuses_bad_arguments(conv):
         conv.edge_reduce("copy", xg, ei, 10)
 
 
-@pytest.mark.parametrize("E,N", [(1, 1), (40, 21), (1023, 7), (1024, 1024), (1025, 40000), (8192, 9134), (12288, 300), (12288, 40000)])
+@pytest.mark.parametrize("E,N", [(1, 1), (40, 21), (1023, 7), (1024, 1024), (1025, 40000), (18744, 9134), (24576, 300), (24576, 40000)])
 def test_one_launch_plan_equals_the_radix_plan(E, N, monkeypatch):
     """csrc/plan.hip plan_small_kernel (one workgroup, counters in LDS) against the radix build: rowptr, perm (stable:
     ascending positions inside every destination) and the companion column, bit for bit; a hub destination included."""
