@@ -1,0 +1,261 @@
+// cluster.hip — the torch_cluster ops the reference lists among what it means to benchmark (ops.txt:33-41: grid_cluster,
+// fps, knn_graph, radius_graph, nearest, random_walk) — SURVEY.md §8(f) rank 4. torch-cluster 1.5.9 (requirements.txt:210)
+// is not in the reference tree: the definitions below are the package's published ones, parity unpinned, oracle in
+// oracle/spatial_oracle.py. Batches are given as CSR pointers over points sorted by batch (ptr [B + 1], int64), the form
+// the package itself converts `batch` vectors to.
+//
+// All of these are small-D geometry (D = 2, 3 coordinates; at most a few hundred thousand points per call) where the
+// distance evaluation is a handful of flops on operands that sit in L2: brute force, one WAVE per query so that the 64
+// lanes sweep the candidates of the query's batch segment together, no data structure to build, and every choice
+// deterministic — ties go to the smaller index, neighbour lists come out in the package's order (knn: ascending distance;
+// radius: ascending candidate index, first max_num_neighbors).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ inline float dist2(const T* __restrict__ a, const T* __restrict__ b, int D) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float t = Elem<T>::load(a + d) - Elem<T>::load(b + d);
+        s += t * t;
+    }
+    return s;
+}
+// 1 - cos(a, b), as knn(..., cosine=True)
+template <typename T>
+__device__ inline float cos_dist(const T* __restrict__ a, const T* __restrict__ b, int D) {
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float u = Elem<T>::load(a + d), v = Elem<T>::load(b + d);
+        ab += u * v; aa += u * u; bb += v * v;
+    }
+    return 1.f - ab / (sqrtf(aa) * sqrtf(bb));
+}
+
+// segment b with ptr[b] <= i < ptr[b + 1] (B small: binary search over the pointer)
+__device__ inline int segment_of(const int64_t* __restrict__ ptr, int B, int64_t i) {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// lexicographic (distance, index) minimum across the wave
+__device__ inline void wave_min_pair(float& d, int64_t& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float od = __shfl_xor(d, o);
+        const int64_t oi = __shfl_xor(i, o);
+        if (od < d || (od == d && oi < i)) { d = od; i = oi; }
+    }
+}
+
+// ---- grid_cluster: voxel id of every point ----
+template <typename T>
+__global__ void grid_cluster_kernel(const T* __restrict__ pos, int64_t N, int D, const double* __restrict__ size,
+                                    const double* __restrict__ start, const double* __restrict__ end, int64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = 0, k = 1;
+        for (int d = 0; d < D; ++d) {
+            // the package computes in pos's own type: (pos - start) / size truncated; voxels per axis = trunc((end - start) / size) + 1
+            const float p = Elem<T>::load(pos + i * D + d);
+            c += (int64_t)((p - (float)start[d]) / (float)size[d]) * k;
+            k *= (int64_t)(((float)end[d] - (float)start[d]) / (float)size[d]) + 1;
+        }
+        out[i] = c;
+    }
+}
+
+// ---- knn / nearest: wave per query, k rounds of "smallest (distance, index) after the previous pick" ----
+template <typename T, bool COSINE>
+__global__ __launch_bounds__(256) void knn_kernel(const T* __restrict__ x, const T* __restrict__ y, const int64_t* __restrict__ ptr_x,
+                                                  const int64_t* __restrict__ ptr_y, int B, int64_t Ny, int D, int k,
+                                                  int64_t* __restrict__ col) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t qy = wave0; qy < Ny; qy += nwaves) {
+        const int b = segment_of(ptr_y, B, qy);
+        const int64_t xb = ptr_x[b], xe = ptr_x[b + 1];
+        const T* yq = y + qy * D;
+        float last_d = -__builtin_huge_valf();
+        int64_t last_i = -1;
+        for (int r = 0; r < k; ++r) {
+            float best_d = __builtin_huge_valf();
+            int64_t best_i = INT64_MAX;
+            for (int64_t i = xb + lane; i < xe; i += 64) {
+                const float d = COSINE ? cos_dist<T>(x + i * D, yq, D) : dist2<T>(x + i * D, yq, D);
+                const bool after = d > last_d || (d == last_d && i > last_i);
+                if (after && (d < best_d || (d == best_d && i < best_i))) { best_d = d; best_i = i; }
+            }
+            wave_min_pair(best_d, best_i);
+            if (lane == 0) col[qy * k + r] = best_i == INT64_MAX ? -1 : best_i;   // fewer than k candidates: -1 from here on
+            last_d = best_d;
+            last_i = best_i;
+            if (best_i == INT64_MAX) {
+                for (int r2 = r + 1 + lane; r2 < k; r2 += 64) col[qy * k + r2] = -1;
+                break;
+            }
+        }
+    }
+}
+
+// ---- radius: wave per query, candidates in index order, the first `max_nb` with squared distance < r^2 ----
+template <typename T>
+__global__ __launch_bounds__(256) void radius_kernel(const T* __restrict__ x, const T* __restrict__ y, const int64_t* __restrict__ ptr_x,
+                                                     const int64_t* __restrict__ ptr_y, int B, int64_t Ny, int D, float r2, int max_nb,
+                                                     int64_t* __restrict__ col) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t qy = wave0; qy < Ny; qy += nwaves) {
+        const int b = segment_of(ptr_y, B, qy);
+        const int64_t xb = ptr_x[b], xe = ptr_x[b + 1];
+        const T* yq = y + qy * D;
+        int count = 0;
+        for (int64_t base = xb; base < xe && count < max_nb; base += 64) {
+            const int64_t i = base + lane;
+            const bool hit = i < xe && dist2<T>(x + i * D, yq, D) < r2;
+            const uint64_t m = __ballot(hit);
+            const int pos = count + __popcll(m & ((1ull << lane) - 1));
+            if (hit && pos < max_nb) col[qy * max_nb + pos] = i;
+            count += __popcll(m);
+        }
+        if (count > max_nb) count = max_nb;
+        for (int p = count + lane; p < max_nb; p += 64) col[qy * max_nb + p] = -1;
+    }
+}
+
+// ---- fps: one workgroup per batch segment; dist[] = squared distance to the nearest chosen point so far ----
+template <typename T>
+__global__ __launch_bounds__(1024) void fps_kernel(const T* __restrict__ x, const int64_t* __restrict__ ptr, const int64_t* __restrict__ out_ptr,
+                                                   const int64_t* __restrict__ start, int D, float* __restrict__ dist,
+                                                   int64_t* __restrict__ out) {
+    __shared__ float s_d[16];
+    __shared__ int64_t s_i[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t xb = ptr[b], xe = ptr[b + 1];
+    const int64_t ob = out_ptr[b], oe = out_ptr[b + 1];
+    if (ob == oe || xb == xe) return;
+    int64_t cur = start[b];
+    if (t == 0) out[ob] = cur;
+    for (int64_t i = xb + t; i < xe; i += 1024) dist[i] = __builtin_huge_valf();
+    for (int64_t m = ob + 1; m < oe; ++m) {
+        float best_d = -1.f;
+        int64_t best_i = INT64_MAX;
+        for (int64_t i = xb + t; i < xe; i += 1024) {
+            const float d = fminf(dist[i], dist2<T>(x + i * D, x + cur * D, D));
+            dist[i] = d;
+            if (d > best_d || (d == best_d && i < best_i)) { best_d = d; best_i = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {   // farthest point; ties to the smaller index (torch.argmax's first maximum)
+            const float od = __shfl_xor(best_d, o);
+            const int64_t oi = __shfl_xor(best_i, o);
+            if (od > best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
+        }
+        if (lane == 0) { s_d[wave] = best_d; s_i[wave] = best_i; }
+        __syncthreads();
+        best_d = s_d[0]; best_i = s_i[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w)
+            if (s_d[w] > best_d || (s_d[w] == best_d && s_i[w] < best_i)) { best_d = s_d[w]; best_i = s_i[w]; }
+        __syncthreads();
+        cur = best_i;
+        if (t == 0) out[m] = cur;
+    }
+}
+
+// ---- random_walk: uniform next neighbour from a CSR adjacency; walkers without neighbours stay where they are ----
+__device__ inline uint32_t mix32(uint64_t z) {   // splitmix64 finaliser: counter-based, one draw per (seed, walker, step)
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+__global__ void random_walk_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col, const int64_t* __restrict__ start,
+                                   int64_t S, int L, uint64_t seed, int64_t* __restrict__ out) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < S; w += (int64_t)gridDim.x * blockDim.x) {
+        int64_t cur = start[w];
+        out[w * (L + 1)] = cur;
+        for (int l = 0; l < L; ++l) {
+            const int64_t beg = rowptr[cur], deg = rowptr[cur + 1] - beg;
+            if (deg > 0) {
+                const uint32_t r = mix32(seed ^ ((uint64_t)w * 0x100000001b3ull + (uint64_t)l));
+                cur = col[beg + (int64_t)(((uint64_t)r * (uint64_t)deg) >> 32)];
+            }
+            out[w * (L + 1) + l + 1] = cur;
+        }
+    }
+}
+
+}  // namespace
+
+#define GNNOPS_BY_DTYPE(dtype, CALL, what)                                   \
+    switch (dtype) {                                                         \
+        case GNNOPS_F32: { using T = float; CALL; } break;                   \
+        case GNNOPS_F16: { using T = __half; CALL; } break;                  \
+        case GNNOPS_BF16: { using T = __hip_bfloat16; CALL; } break;         \
+        default: gnnops_set_error(what ": unknown dtype %d", dtype); return GNNOPS_EINVAL; \
+    }
+
+extern "C" int gnnops_grid_cluster(const void* pos, int64_t N, int D, const double* d_size, const double* d_start, const double* d_end,
+                                   int64_t* cluster, int dtype, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(N >= 0 && D >= 1 && D <= 16, GNNOPS_EINVAL, "grid_cluster: bad shape");
+    if (N == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(pos && d_size && d_start && d_end && cluster, GNNOPS_EINVAL, "grid_cluster: null pointer");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(N, 256));
+    GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((grid_cluster_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)pos, N, D, d_size,
+                                              d_start, d_end, cluster), "grid_cluster")
+    return gnnops_check_launch("grid_cluster");
+}
+
+extern "C" int gnnops_knn(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,
+                          int k, int cosine, int64_t* col, int dtype, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(Ny >= 0 && D >= 1 && k >= 1 && batches >= 1 && batches < (1 << 30), GNNOPS_EINVAL, "knn: bad shape");
+    if (Ny == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(x && y && ptr_x && ptr_y && col, GNNOPS_EINVAL, "knn: null pointer");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(Ny, 4), 256 * 32);
+    if (cosine) {
+        GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((knn_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y, ptr_x,
+                                                  ptr_y, (int)batches, Ny, D, k, col), "knn")
+    } else {
+        GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((knn_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y, ptr_x,
+                                                  ptr_y, (int)batches, Ny, D, k, col), "knn")
+    }
+    return gnnops_check_launch("knn");
+}
+
+extern "C" int gnnops_radius(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,
+                             double r, int max_num_neighbors, int64_t* col, int dtype, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(Ny >= 0 && D >= 1 && max_num_neighbors >= 1 && batches >= 1 && batches < (1 << 30), GNNOPS_EINVAL, "radius: bad shape");
+    if (Ny == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(x && y && ptr_x && ptr_y && col, GNNOPS_EINVAL, "radius: null pointer");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(Ny, 4), 256 * 32);
+    const float r2 = (float)(r * r);
+    GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((radius_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y, ptr_x, ptr_y,
+                                              (int)batches, Ny, D, r2, max_num_neighbors, col), "radius")
+    return gnnops_check_launch("radius");
+}
+
+extern "C" int gnnops_fps(const void* x, const int64_t* ptr, const int64_t* out_ptr, const int64_t* start, int64_t batches, int D,
+                          float* dist_workspace, int64_t* out, int dtype, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(batches >= 0 && batches < (1 << 30) && D >= 1, GNNOPS_EINVAL, "fps: bad shape");
+    if (batches == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(x && ptr && out_ptr && start && dist_workspace && out, GNNOPS_EINVAL, "fps: null pointer");
+    GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((fps_kernel<T>), dim3((unsigned)batches), dim3(1024), 0, (hipStream_t)s, (const T*)x, ptr, out_ptr,
+                                              start, D, dist_workspace, out), "fps")
+    return gnnops_check_launch("fps");
+}
+
+extern "C" int gnnops_random_walk(const int64_t* rowptr, const int64_t* col, const int64_t* start, int64_t walkers, int walk_length,
+                                  uint64_t seed, int64_t* out, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(walkers >= 0 && walk_length >= 0, GNNOPS_EINVAL, "random_walk: bad shape");
+    if (walkers == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(rowptr && start && out && col, GNNOPS_EINVAL, "random_walk: null pointer");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(walkers, 256));
+    hipLaunchKernelGGL(random_walk_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, rowptr, col, start, walkers, walk_length, seed, out);
+    return gnnops_check_launch("random_walk");
+}

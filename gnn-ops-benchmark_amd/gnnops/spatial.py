@@ -1,0 +1,296 @@
+"""The remaining ops of the reference's list (ops.txt:17-19, 29-41) behind the packages' own
+signatures: torch_spline_conv.{spline_basis, spline_weighting, spline_conv} and torch_cluster.{grid_cluster, fps, knn,
+knn_graph, radius, radius_graph, nearest, random_walk}. The import seams are the sibling packages ``torch_spline_conv`` and
+``torch_cluster`` in this directory. Kernels: csrc/spline.hip, csrc/cluster.hip. Parity unpinned (neither package nor any
+output of it is in the reference tree): oracle/spatial_oracle.py restates the published definitions.
+
+Forward only. Device tensors only — CPU tensors are refused, not emulated."""
+import math
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .ops import _dtype_code, _require_gpu, _stream, get_plan
+from .sparse import _csr_arrays
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# torch_spline_conv
+# ---------------------------------------------------------------------------------------------------------------------
+_host_cache = {}   # id(tensor) -> (weakref-free key, host copy): kernel_size / is_open_spline are tiny and constant per layer
+
+
+def _host(t, dtype):
+    """kernel_size / is_open_spline as host arrays (the C entry points read them while launching). A device tensor is read
+    back once per (tensor object, version) — one synchronisation when a layer is first used, none afterwards."""
+    if t.device.type == "cpu":
+        return t.to(dtype).contiguous()
+    key = (id(t), t._version, t.data_ptr())
+    hit = _host_cache.get(id(t))
+    if hit is None or hit[0] != key:
+        if len(_host_cache) > 64:
+            _host_cache.clear()
+        hit = (key, t.detach().to("cpu", dtype).contiguous())
+        _host_cache[id(t)] = hit
+    return hit[1]
+
+
+def spline_basis(pseudo, kernel_size, is_open_spline, degree):
+    """torch_spline_conv.spline_basis (torch.ops.torch_spline_conv.spline_basis, ops.txt:19): (basis [E, S], weight_index [E, S])."""
+    _require_gpu(pseudo)
+    ops._refuse_grad("spline_basis", pseudo)
+    if pseudo.dim() == 1:
+        pseudo = pseudo.unsqueeze(-1)
+    pseudo = pseudo.contiguous()
+    E, D = pseudo.shape
+    dt = _dtype_code(pseudo, "spline_basis")
+    ks, op = _host(kernel_size, torch.int64), _host(is_open_spline, torch.uint8)
+    if ks.numel() != D or op.numel() != D:
+        raise RuntimeError("spline_basis: kernel_size and is_open_spline need one entry per pseudo-coordinate")
+    S = (degree + 1) ** D
+    basis = torch.empty((E, S), dtype=pseudo.dtype, device=pseudo.device)
+    wi = torch.empty((E, S), dtype=torch.int64, device=pseudo.device)
+    with torch.cuda.device(pseudo.device):
+        check(_lib.load().gnnops_spline_basis(pseudo.data_ptr(), ks.data_ptr(), op.data_ptr(), E, D, int(degree), basis.data_ptr(),
+                                              wi.data_ptr(), dt, _stream()), "spline_basis")
+    return basis, wi
+
+
+def spline_weighting(x, weight, basis, weight_index):
+    """torch_spline_conv.spline_weighting (ops.txt:18): x [E, Min], weight [K, Min, Mout] -> [E, Mout]."""
+    _require_gpu(x, weight, basis, weight_index)
+    ops._refuse_grad("spline_weighting", x, weight, basis)
+    if x.dim() != 2 or weight.dim() != 3 or weight.size(1) != x.size(1) or basis.shape != weight_index.shape or basis.size(0) != x.size(0):
+        raise RuntimeError("spline_weighting: x [E, Min], weight [K, Min, Mout], basis / weight_index [E, S]")
+    if not (x.dtype == weight.dtype == basis.dtype) or weight_index.dtype != torch.int64:
+        raise RuntimeError("spline_weighting: x, weight and basis share a dtype; weight_index is int64")
+    dt = _dtype_code(x, "spline_weighting")
+    x, weight, basis, weight_index = x.contiguous(), weight.contiguous(), basis.contiguous(), weight_index.contiguous()
+    E, Min = x.shape
+    Mout = weight.size(2)
+    out = torch.empty((E, Mout), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().gnnops_spline_weighting(x.data_ptr(), weight.data_ptr(), basis.data_ptr(), weight_index.data_ptr(),
+                                                  out.data_ptr(), E, Min, Mout, basis.size(1), dt, _stream()), "spline_weighting")
+    return out
+
+
+def spline_conv(x, edge_index, pseudo, weight, kernel_size, is_open_spline, degree=1, norm=True, root_weight=None, bias=None):
+    """torch_spline_conv.spline_conv (ops.txt:31): messages x[edge_index[1]] blended through the B-spline kernel, summed at
+    edge_index[0] (divided by that row's degree when ``norm``), + x @ root_weight + bias. One pass over the plan of
+    edge_index[0]; neither the basis tensors nor the [E, Mout] messages are materialised."""
+    _require_gpu(x, edge_index, pseudo, weight, root_weight, bias)
+    ops._refuse_grad("spline_conv", x, pseudo, weight, root_weight, bias)
+    if x.dim() == 1:
+        x = x.unsqueeze(-1)
+    if pseudo.dim() == 1:
+        pseudo = pseudo.unsqueeze(-1)
+    if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
+        raise ValueError("spline_conv: edge_index must be int64 [2, E]")
+    x, pseudo, weight = x.contiguous(), pseudo.contiguous(), weight.contiguous()
+    edge_index = edge_index.contiguous()
+    N, Min = x.shape
+    E, D = pseudo.shape
+    if edge_index.size(1) != E or weight.dim() != 3 or weight.size(1) != Min:
+        raise RuntimeError("spline_conv: pseudo has one row per edge; weight is [K, Min, Mout]")
+    Mout = weight.size(2)
+    dt = _dtype_code(x, "spline_conv")
+    for t in (pseudo, weight, root_weight, bias):
+        if t is not None and t.dtype != x.dtype:
+            raise RuntimeError("spline_conv: operands must have the same dtype")
+    ks, op = _host(kernel_size, torch.int64), _host(is_open_spline, torch.uint8)
+    if ks.numel() != D or op.numel() != D:
+        raise RuntimeError("spline_conv: kernel_size and is_open_spline need one entry per pseudo-coordinate")
+    row, col = edge_index[0], edge_index[1]
+    plan = get_plan(row, N, owner=edge_index, tag=0, companion=col)
+    if plan.col is not None or E == 0:
+        src = plan.col if E else col
+    else:
+        src, _ = _csr_arrays(plan, col, None, owner=edge_index, tag=1)
+    out = torch.empty((N, Mout), dtype=x.dtype, device=x.device)
+    ptr = lambda t: t.contiguous().data_ptr() if t is not None else None   # noqa: E731
+    root_c = root_weight.contiguous() if root_weight is not None else None
+    bias_c = bias.contiguous() if bias is not None else None
+    with torch.cuda.device(x.device):
+        check(_lib.load().gnnops_spline_conv(x.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(), src.data_ptr(), pseudo.data_ptr(),
+                                             weight.data_ptr(), ks.data_ptr(), op.data_ptr(), D, int(degree), ptr(root_c), ptr(bias_c),
+                                             out.data_ptr(), N, E, Min, Mout, 1 if norm else 0, dt, _stream()), "spline_conv")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# torch_cluster
+# ---------------------------------------------------------------------------------------------------------------------
+def _ptr_of(batch, n, device, batch_size=None):
+    """CSR pointer over points sorted by batch (what the package builds from `batch`); None = one batch of everything."""
+    if batch is None:
+        return torch.tensor([0, n], dtype=torch.int64, device=device)
+    if batch.numel() != n:
+        raise RuntimeError("batch must have one entry per point")
+    B = int(batch.max()) + 1 if batch_size is None and batch.numel() else (batch_size or 1)   # the package reads batch.max() back too
+    ptr = torch.zeros(B + 1, dtype=torch.int64, device=device)
+    ptr[1:] = torch.bincount(batch, minlength=B).cumsum(0)
+    return ptr
+
+
+def _points(t, what):
+    _require_gpu(t)
+    t = t.view(-1, 1) if t.dim() == 1 else t
+    if t.dim() != 2:
+        raise RuntimeError(f"{what}: points must be [N, D]")
+    return t.contiguous()
+
+
+def grid_cluster(pos, size, start=None, end=None):
+    """torch_cluster.grid_cluster(pos, size, start=None, end=None) -> voxel id per point (ops.txt:36)."""
+    pos = _points(pos, "grid_cluster")
+    dt = _dtype_code(pos, "grid_cluster")
+    N, D = pos.shape
+    dev = pos.device
+    as_dev = lambda v: torch.as_tensor(v, dtype=torch.float64, device=dev).reshape(-1).contiguous()   # noqa: E731
+    size = as_dev(size)
+    start = as_dev(start) if start is not None else pos.min(dim=0).values.to(torch.float64)
+    end = as_dev(end) if end is not None else pos.max(dim=0).values.to(torch.float64)
+    if not (size.numel() == start.numel() == end.numel() == D):
+        raise RuntimeError("grid_cluster: size, start and end need one entry per coordinate")
+    out = torch.empty(N, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().gnnops_grid_cluster(pos.data_ptr(), N, D, size.data_ptr(), start.contiguous().data_ptr(), end.contiguous().data_ptr(),
+                                              out.data_ptr(), dt, _stream()), "grid_cluster")
+    return out
+
+
+def fps(x, batch=None, ratio=0.5, random_start=True):
+    """torch_cluster.fps(x, batch=None, ratio=0.5, random_start=True) -> indices of the sampled points, batch after batch:
+    ceil(ratio * n_b) per batch, each the point farthest from those already chosen (ties: the smaller index)."""
+    x = _points(x, "fps")
+    dt = _dtype_code(x, "fps")
+    N, D = x.shape
+    dev = x.device
+    ptr = _ptr_of(batch, N, dev)
+    deg = ptr[1:] - ptr[:-1]
+    k = torch.ceil(deg.to(torch.float64) * float(ratio)).to(torch.int64)
+    out_ptr = torch.zeros_like(ptr)
+    out_ptr[1:] = k.cumsum(0)
+    total = int(out_ptr[-1])                                   # the package sizes its output the same way (one read-back)
+    if random_start:
+        start = ptr[:-1] + (torch.rand(deg.numel(), device=dev) * deg.to(torch.float32)).to(torch.int64).clamp_(max=(deg - 1).clamp_(min=0))
+    else:
+        start = ptr[:-1].clone()
+    out = torch.empty(total, dtype=torch.int64, device=dev)
+    dist = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().gnnops_fps(x.data_ptr(), ptr.data_ptr(), out_ptr.data_ptr(), start.data_ptr(), ptr.numel() - 1, D, dist.data_ptr(),
+                                     out.data_ptr(), dt, _stream()), "fps")
+    return out
+
+
+def _pair_ptrs(x, y, batch_x, batch_y):
+    if (batch_x is None) != (batch_y is None):
+        raise RuntimeError("give both batch_x and batch_y or neither")
+    if batch_x is None:
+        return _ptr_of(None, x.size(0), x.device), _ptr_of(None, y.size(0), x.device)
+    B = int(max(batch_x.max(), batch_y.max())) + 1 if batch_x.numel() and batch_y.numel() else 1
+    return _ptr_of(batch_x, x.size(0), x.device, B), _ptr_of(batch_y, y.size(0), x.device, B)
+
+
+def _pairs(col, k):
+    """[Ny, k] neighbour table with -1 for 'none' -> the package's [2, M] (row = query index, col = neighbour index)."""
+    ny = col.size(0)
+    row = torch.arange(ny, device=col.device).view(-1, 1).expand(ny, k).reshape(-1)
+    col = col.reshape(-1)
+    mask = col >= 0
+    return torch.stack([row[mask], col[mask]], dim=0)
+
+
+def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
+    """torch_cluster.knn(x, y, k, batch_x, batch_y, cosine): for every y its k nearest x of the same batch, nearest first:
+    int64 [2, M] = (index into y, index into x)."""
+    x, y = _points(x, "knn"), _points(y, "knn")
+    if x.size(1) != y.size(1) or x.dtype != y.dtype:
+        raise RuntimeError("knn: x and y need the same width and dtype")
+    dt = _dtype_code(x, "knn")
+    ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
+    col = torch.empty((y.size(0), k), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().gnnops_knn(x.data_ptr(), y.data_ptr(), ptr_x.data_ptr(), ptr_y.data_ptr(), ptr_x.numel() - 1, y.size(0), x.size(1),
+                                     int(k), 1 if cosine else 0, col.data_ptr(), dt, _stream()), "knn")
+    return _pairs(col, k)
+
+
+def knn_graph(x, k, batch=None, loop=False, flow="source_to_target", cosine=False, num_workers=1):
+    """torch_cluster.knn_graph (ops.txt:38): edges from the k nearest neighbours to each point."""
+    if flow not in ("source_to_target", "target_to_source"):
+        raise ValueError(flow)
+    ei = knn(x, x, k if loop else k + 1, batch, batch, cosine)
+    row, col = (ei[1], ei[0]) if flow == "source_to_target" else (ei[0], ei[1])
+    if not loop:
+        mask = row != col
+        row, col = row[mask], col[mask]
+    return torch.stack([row, col], dim=0)
+
+
+def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32, num_workers=1):
+    """torch_cluster.radius: for every y the x of the same batch within distance r (at most max_num_neighbors, by index)."""
+    x, y = _points(x, "radius"), _points(y, "radius")
+    if x.size(1) != y.size(1) or x.dtype != y.dtype:
+        raise RuntimeError("radius: x and y need the same width and dtype")
+    dt = _dtype_code(x, "radius")
+    ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
+    col = torch.empty((y.size(0), max_num_neighbors), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().gnnops_radius(x.data_ptr(), y.data_ptr(), ptr_x.data_ptr(), ptr_y.data_ptr(), ptr_x.numel() - 1, y.size(0), x.size(1),
+                                        float(r), int(max_num_neighbors), col.data_ptr(), dt, _stream()), "radius")
+    return _pairs(col, max_num_neighbors)
+
+
+def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="source_to_target", num_workers=1):
+    """torch_cluster.radius_graph (ops.txt:39)."""
+    if flow not in ("source_to_target", "target_to_source"):
+        raise ValueError(flow)
+    ei = radius(x, x, r, batch, batch, max_num_neighbors if loop else max_num_neighbors + 1)
+    row, col = (ei[1], ei[0]) if flow == "source_to_target" else (ei[0], ei[1])
+    if not loop:
+        mask = row != col
+        row, col = row[mask], col[mask]
+    return torch.stack([row, col], dim=0)
+
+
+def nearest(x, y, batch_x=None, batch_y=None):
+    """torch_cluster.nearest(x, y, batch_x, batch_y) (ops.txt:40): for every x the index of its nearest y of the same batch."""
+    x, y = _points(x, "nearest"), _points(y, "nearest")
+    dt = _dtype_code(x, "nearest")
+    ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
+    col = torch.empty((x.size(0), 1), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):   # the k = 1 search with the roles swapped: queries are x, candidates y
+        check(_lib.load().gnnops_knn(y.data_ptr(), x.data_ptr(), ptr_y.data_ptr(), ptr_x.data_ptr(), ptr_x.numel() - 1, x.size(0), x.size(1),
+                                     1, 0, col.data_ptr(), dt, _stream()), "nearest")
+    return col.view(-1)
+
+
+def random_walk(row, col, start, walk_length, p=1.0, q=1.0, coalesced=True, num_nodes=None, seed=None):
+    """torch_cluster.random_walk(row, col, start, walk_length, p=1, q=1, coalesced, num_nodes) (ops.txt:41): [len(start),
+    walk_length + 1] node ids; each step moves to a uniformly drawn neighbour (a node without neighbours stays). p = q = 1
+    only (the node2vec bias needs rejection sampling, not built). ``seed`` (extra): fixes the draws; default from torch's RNG."""
+    if p != 1.0 or q != 1.0:
+        raise NotImplementedError("gnnops.random_walk: p and q must be 1")
+    _require_gpu(row, col, start)
+    if num_nodes is None:
+        num_nodes = int(max(row.max(), col.max())) + 1 if row.numel() else int(start.max()) + 1
+    # CSR adjacency from the plan of `row` (stable: a row's neighbours keep the caller's order; `coalesced` only says whether
+    # the caller already sorted them, which a uniform draw does not care about)
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=row.device)
+    if row.numel():
+        plan = ops.Plan(row.contiguous(), num_nodes, col.contiguous())
+        rowptr = plan.rowptr.to(torch.int64)
+        col = plan.col if plan.col is not None else col[plan.perm[: row.numel()].long()]
+    start = start.contiguous()
+    out = torch.empty((start.numel(), walk_length + 1), dtype=torch.int64, device=row.device)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    colc = col.contiguous() if col.numel() else torch.zeros(1, dtype=torch.int64, device=row.device)
+    with torch.cuda.device(row.device):
+        check(_lib.load().gnnops_random_walk(rowptr.data_ptr(), colc.data_ptr(), start.data_ptr(), start.numel(), int(walk_length), int(seed),
+                                             out.data_ptr(), _stream()), "random_walk")
+    return out

@@ -389,6 +389,45 @@ int gnnops_edge_reduce(int functor, const void* q, int64_t ldq, const void* p, i
                        const int* scalers, int n_scalers, float avg_deg_log, float avg_deg_lin, int dtype,
                        gnnops_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The remaining ops of the reference's list (ops.txt:17-19, 29-41) - SURVEY.md 8(f) rank 4. Neither package is in the
+ * reference tree (torch-spline-conv 1.2.1, torch-cluster 1.5.9: requirements.txt:214, :210) and the reference has no
+ * script or output for them: the packages' published definitions, parity unpinned (oracle/spatial_oracle.py).
+ *
+ * torch_spline_conv  (csrc/spline.hip has the formulas)
+ *   gnnops_spline_basis      pseudo [E, D] -> basis [E, S] (dtype), weight_index [E, S] int64, S = (degree + 1)^D <= 64;
+ *                            kernel_size int64 [D] and is_open_spline uint8 [D] are HOST arrays
+ *   gnnops_spline_weighting  out[e, o] = sum_s basis[e, s] * sum_i x[e, i] * weight[weight_index[e, s], i, o]
+ *   gnnops_spline_conv       the whole layer per destination row in one pass: (rowptr, perm) = plan of edge_index[0],
+ *                            src int64 [E] = edge_index[1] in plan order, pseudo [E, D] in edge order; norm != 0 divides by
+ *                            the row's degree; root_weight [Min, Mout] and bias [Mout] optional
+ * torch_cluster  (batches as CSR pointers ptr [batches + 1] int64 over points sorted by batch; all arrays on the device)
+ *   gnnops_grid_cluster  voxel id per point; size / start / end: device double [D]
+ *   gnnops_knn           col [Ny, k] = the k nearest x of every y within its batch, ascending (distance, index); -1 = none
+ *   gnnops_radius        col [Ny, max] = the first max x (ascending index) with |x - y|^2 < r^2; -1 = none
+ *   gnnops_fps           farthest point sampling per batch: out[out_ptr[b] .. out_ptr[b+1]) starting from start[b];
+ *                        dist_workspace float [N]
+ *   gnnops_random_walk   out [walkers, walk_length + 1]: uniform next neighbour over a CSR adjacency (int64 rowptr, col)
+ * ------------------------------------------------------------------------------------------- */
+int gnnops_spline_basis(const void* pseudo, const int64_t* kernel_size, const uint8_t* is_open_spline, int64_t E, int D,
+                        int degree, void* basis, int64_t* weight_index, int dtype, gnnops_stream_t stream);
+int gnnops_spline_weighting(const void* x, const void* weight, const void* basis, const int64_t* weight_index, void* out,
+                            int64_t E, int64_t Min, int64_t Mout, int64_t S, int dtype, gnnops_stream_t stream);
+int gnnops_spline_conv(const void* x, const int32_t* rowptr, const int32_t* perm, const int64_t* src, const void* pseudo,
+                       const void* weight, const int64_t* kernel_size, const uint8_t* is_open_spline, int D, int degree,
+                       const void* root_weight, const void* bias, void* out, int64_t N, int64_t E, int64_t Min, int64_t Mout,
+                       int norm, int dtype, gnnops_stream_t stream);
+int gnnops_grid_cluster(const void* pos, int64_t N, int D, const double* d_size, const double* d_start, const double* d_end,
+                        int64_t* cluster, int dtype, gnnops_stream_t stream);
+int gnnops_knn(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,
+               int k, int cosine, int64_t* col, int dtype, gnnops_stream_t stream);
+int gnnops_radius(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,
+                  double r, int max_num_neighbors, int64_t* col, int dtype, gnnops_stream_t stream);
+int gnnops_fps(const void* x, const int64_t* ptr, const int64_t* out_ptr, const int64_t* start, int64_t batches, int D,
+               float* dist_workspace, int64_t* out, int dtype, gnnops_stream_t stream);
+int gnnops_random_walk(const int64_t* rowptr, const int64_t* col, const int64_t* start, int64_t walkers, int walk_length,
+                       uint64_t seed, int64_t* out, gnnops_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

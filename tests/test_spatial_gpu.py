@@ -1,0 +1,217 @@
+"""GPU parity for the remaining ops of the reference's list (ops.txt:17-19, 29-41): torch_spline_conv's
+spline_basis / spline_weighting / spline_conv and torch_cluster's grid_cluster / fps / knn(_graph) / radius(_graph) / nearest
+/ random_walk, through the import seams (`from torch_spline_conv import ...`, `from torch_cluster import ...`).
+
+PARITY UNPINNED (oracle/spatial_oracle.py header): neither package nor any output of it is in the reference tree; the oracle
+restates the published definitions. Bars: integer outputs (weight_index, cluster ids, neighbour lists, sampled indices) exact
+— inputs are drawn so that no two candidate distances tie within fp32 rounding, except where a test builds exact ties on
+purpose to pin the smaller-index rule; floating outputs within 1e-5 (fp32) / 4e-3 (fp16) of the value scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ora():
+    from oracle import spatial_oracle
+
+    return spatial_oracle
+
+
+def _f64(t):
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def _close(got, want, tol, what):
+    got = _f64(got)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)
+    assert err <= tol, f"{what}: {err:.3e} > {tol:.1e}"
+
+
+# ---- torch_spline_conv ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("degree", [1, 2, 3])
+@pytest.mark.parametrize("D,kernel_size,is_open", [(1, [5], [1]), (2, [5, 4], [1, 0]), (3, [3, 4, 5], [0, 1, 0])])
+def test_spline_basis_and_weighting(ora, degree, D, kernel_size, is_open):
+    from torch_spline_conv import spline_basis, spline_weighting
+
+    if degree == 3 and D == 3:
+        kernel_size = [4, 4, 5]                 # an open cubic spline needs kernel_size > degree
+    g = torch.Generator().manual_seed(degree * 10 + D)
+    E, Min, Mout = 257, 7, 70
+    pseudo = torch.rand(E, D, generator=g)
+    pseudo[0] = 0.0
+    pseudo[1] = 1.0                              # the closed end wraps around: (floor(v) + k) mod kernel_size
+    ks, op = torch.tensor(kernel_size), torch.tensor(is_open, dtype=torch.uint8)
+    basis, wi = spline_basis(pseudo.cuda(), ks.cuda(), op.cuda(), degree)
+    want_b, want_wi = ora.spline_basis(pseudo.numpy(), kernel_size, is_open, degree)
+    assert basis.shape == (E, (degree + 1) ** D)
+    assert np.array_equal(wi.cpu().numpy(), want_wi)
+    _close(basis, want_b, 1e-5, "basis")
+    assert torch.allclose(basis[2:].sum(1).cpu(), torch.ones(E - 2), atol=1e-5), "a B-spline basis is a partition of unity"
+    K = int(np.prod(kernel_size))
+    x = torch.rand(E, Min, generator=g) - 0.5
+    weight = torch.rand(K, Min, Mout, generator=g) - 0.5
+    for dtype, tol in ((torch.float32, 1e-5), (torch.float16, 4e-3)):
+        out = spline_weighting(x.to(dtype).cuda(), weight.to(dtype).cuda(), basis.to(dtype), wi)
+        want = ora.spline_weighting(_f64(x.to(dtype)), _f64(weight.to(dtype)), _f64(basis.to(dtype)), want_wi)
+        _close(out, want, tol, f"weighting {dtype}")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("norm,root,bias", [(True, True, True), (False, False, False)])
+def test_spline_conv(ora, dtype, tol, norm, root, bias):
+    from torch_spline_conv import spline_conv
+
+    g = torch.Generator().manual_seed(3)
+    N, E, Min, Mout, D = 120, 900, 9, 33, 2
+    ks, op = torch.tensor([5, 5]), torch.tensor([1, 0], dtype=torch.uint8)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[0][ei[0] == 7] = 8                        # row 7 receives nothing
+    x = (torch.rand(N, Min, generator=g) - 0.5).to(dtype)
+    pseudo = torch.rand(E, D, generator=g).to(dtype)
+    weight = (torch.rand(25, Min, Mout, generator=g) - 0.5).to(dtype)
+    rw = (torch.rand(Min, Mout, generator=g) - 0.5).to(dtype) if root else None
+    b = (torch.rand(Mout, generator=g) - 0.5).to(dtype) if bias else None
+    out = spline_conv(x.cuda(), ei.cuda(), pseudo.cuda(), weight.cuda(), ks, op, 1, norm, None if rw is None else rw.cuda(),
+                      None if b is None else b.cuda())
+    want = ora.spline_conv(_f64(x), ei.numpy(), _f64(pseudo), _f64(weight), [5, 5], [1, 0], 1, norm,
+                           None if rw is None else _f64(rw), None if b is None else _f64(b))
+    _close(out, want, tol, "spline_conv")
+    if not (root or bias):
+        assert bool((out[7] == 0).all())
+
+
+# ---- torch_cluster ----------------------------------------------------------------------------------------------------
+def _cloud(seed, n, d, batches):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, d, generator=g)
+    batch = torch.sort(torch.randint(0, batches, (n,), generator=g)).values if batches > 1 else None
+    return x, batch
+
+
+def test_grid_cluster(ora):
+    from torch_cluster import grid_cluster
+
+    x, _ = _cloud(1, 1000, 3, 1)
+    size = [0.21, 0.37, 0.5]
+    got = grid_cluster(x.cuda(), torch.tensor(size).cuda())
+    want = ora.grid_cluster(x.numpy(), size, x.min(0).values.numpy(), x.max(0).values.numpy())
+    assert np.array_equal(got.cpu().numpy(), want)
+    got = grid_cluster(x.cuda(), torch.tensor(size), torch.tensor([-0.5, 0.0, 0.0]), torch.tensor([1.5, 1.0, 2.0]))
+    assert np.array_equal(got.cpu().numpy(), ora.grid_cluster(x.numpy(), size, [-0.5, 0.0, 0.0], [1.5, 1.0, 2.0]))
+    # known answer: 2-D, unit voxels over [0, 3) x [0, 2): id = ix + 3 * iy
+    pos = torch.tensor([[0.5, 0.5], [2.5, 0.5], [1.5, 1.5]])
+    assert grid_cluster(pos.cuda(), torch.tensor([1.0, 1.0]), torch.tensor([0.0, 0.0]), torch.tensor([2.9, 1.9])).tolist() == [0, 2, 4]
+
+
+@pytest.mark.parametrize("batches", [1, 5])
+def test_fps(ora, batches):
+    from torch_cluster import fps
+
+    x, batch = _cloud(2, 700, 3, batches)
+    got = fps(x.cuda(), None if batch is None else batch.cuda(), ratio=0.25, random_start=False)
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(batch.numpy(), minlength=batches))]) if batch is not None else np.array([0, 700])
+    want = ora.fps(x.numpy(), None if batch is None else batch.numpy(), 0.25, ptr[:-1])
+    assert np.array_equal(got.cpu().numpy(), want)
+    rnd = fps(x.cuda(), None if batch is None else batch.cuda(), ratio=0.25, random_start=True)
+    assert rnd.numel() == got.numel() and rnd.unique().numel() == rnd.numel()
+    if batch is not None:                        # every batch keeps its share and its own points
+        assert torch.equal(torch.bincount(batch[rnd.cpu()], minlength=batches), torch.ceil(torch.bincount(batch, minlength=batches) * 0.25).long())
+
+
+@pytest.mark.parametrize("batches,cosine", [(1, False), (4, False), (3, True)])
+def test_knn_and_knn_graph(ora, batches, cosine):
+    from torch_cluster import knn, knn_graph
+
+    x, bx = _cloud(3, 300, 3, batches)
+    y, by = _cloud(4, 90, 3, batches)
+    k = 7
+    got = knn(x.cuda(), y.cuda(), k, None if bx is None else bx.cuda(), None if by is None else by.cuda(), cosine=cosine)
+    want = ora.knn(x.numpy(), y.numpy(), k, None if bx is None else bx.numpy(), None if by is None else by.numpy(), cosine)
+    assert np.array_equal(got.cpu().numpy(), want)
+    if not cosine:
+        g = knn_graph(x.cuda(), 4, None if bx is None else bx.cuda())
+        w = ora.knn(x.numpy(), x.numpy(), 5, None if bx is None else bx.numpy(), None if bx is None else bx.numpy())
+        w = np.stack([w[1], w[0]])[:, w[0] != w[1]]     # flow source_to_target: (neighbour, point), self loops dropped
+        assert np.array_equal(g.cpu().numpy(), w)
+        assert torch.equal(torch.bincount(g[1].cpu(), minlength=300), torch.full((300,), 4))
+
+
+def test_knn_fewer_candidates_than_k_and_exact_ties():
+    from torch_cluster import knn
+
+    x = torch.tensor([[0.0, 0.0], [2.0, 0.0], [0.0, 2.0], [5.0, 5.0]])
+    bx = torch.tensor([0, 0, 0, 1])
+    y = torch.tensor([[1.0, 1.0], [5.0, 4.0]])
+    by = torch.tensor([0, 1])
+    got = knn(x.cuda(), y.cuda(), 2, bx.cuda(), by.cuda())
+    # y0 is equidistant from x0, x1, x2: the two smaller indices; y1's batch holds one point only
+    assert got.cpu().tolist() == [[0, 0, 1], [0, 1, 3]]
+
+
+@pytest.mark.parametrize("batches", [1, 4])
+def test_radius_and_radius_graph(ora, batches):
+    from torch_cluster import radius, radius_graph
+
+    x, bx = _cloud(5, 400, 3, batches)
+    y, by = _cloud(6, 60, 3, batches)
+    for r, cap in ((0.25, 32), (0.6, 5)):
+        got = radius(x.cuda(), y.cuda(), r, None if bx is None else bx.cuda(), None if by is None else by.cuda(), max_num_neighbors=cap)
+        want = ora.radius(x.numpy(), y.numpy(), r, None if bx is None else bx.numpy(), None if by is None else by.numpy(), cap)
+        assert np.array_equal(got.cpu().numpy(), want), (r, cap)
+    g = radius_graph(x.cuda(), 0.2, None if bx is None else bx.cuda(), max_num_neighbors=64)
+    w = ora.radius(x.numpy(), x.numpy(), 0.2, None if bx is None else bx.numpy(), None if bx is None else bx.numpy(), 65)
+    w = np.stack([w[1], w[0]])[:, w[0] != w[1]]
+    assert np.array_equal(g.cpu().numpy(), w)
+
+
+def test_nearest(ora):
+    from torch_cluster import nearest
+
+    x, bx = _cloud(7, 500, 2, 3)
+    y, by = _cloud(8, 40, 2, 3)
+    got = nearest(x.cuda(), y.cuda(), bx.cuda(), by.cuda())
+    assert np.array_equal(got.cpu().numpy(), ora.nearest(x.numpy(), y.numpy(), bx.numpy(), by.numpy()))
+    got = nearest(x.cuda(), y.cuda())
+    assert np.array_equal(got.cpu().numpy(), ora.nearest(x.numpy(), y.numpy()))
+
+
+def test_random_walk_properties():
+    """Random by nature: every step goes to a neighbour of the current node, a node without neighbours stays, the same
+    seed gives the same walks, and the draws are close to uniform over a node's neighbours."""
+    from torch_cluster import random_walk
+
+    g = torch.Generator().manual_seed(9)
+    n, e = 200, 1500
+    row, col = torch.randint(0, n - 1, (e,), generator=g), torch.randint(0, n, (e,), generator=g)   # node n-1 has no out-edge
+    start = torch.arange(n).repeat(4)
+    walks = random_walk(row.cuda(), col.cuda(), start.cuda(), 12, num_nodes=n, seed=5).cpu()
+    assert walks.shape == (4 * n, 13) and torch.equal(walks[:, 0], start)
+    adj = torch.zeros(n, n, dtype=torch.bool)
+    adj[row, col] = True
+    has_out = adj.any(1)
+    a, b = walks[:, :-1].reshape(-1), walks[:, 1:].reshape(-1)
+    assert bool((adj[a, b] | (~has_out[a] & (a == b))).all())
+    assert torch.equal(walks, random_walk(row.cuda(), col.cuda(), start.cuda(), 12, num_nodes=n, seed=5).cpu())
+    assert not torch.equal(walks, random_walk(row.cuda(), col.cuda(), start.cuda(), 12, num_nodes=n, seed=6).cpu())
+    # uniformity: a node with 4 distinct neighbours, 40 000 single steps
+    r2, c2 = torch.tensor([0, 0, 0, 0]), torch.tensor([1, 2, 3, 4])
+    one = random_walk(r2.cuda(), c2.cuda(), torch.zeros(40000, dtype=torch.int64).cuda(), 1, num_nodes=5, seed=1)[:, 1].cpu()
+    freq = torch.bincount(one, minlength=5)[1:].float() / 40000
+    assert bool(((freq - 0.25).abs() < 0.01).all()), freq
+    with pytest.raises(NotImplementedError):
+        random_walk(row.cuda(), col.cuda(), start.cuda(), 3, p=2.0)
+
+
+def test_spatial_ops_refuse_cpu_tensors():
+    from torch_cluster import knn
+    from torch_spline_conv import spline_basis
+
+    with pytest.raises((RuntimeError, ValueError)):
+        knn(torch.rand(5, 2), torch.rand(3, 2), 2)
+    with pytest.raises((RuntimeError, ValueError)):
+        spline_basis(torch.rand(5, 2), torch.tensor([3, 3]), torch.tensor([1, 1], dtype=torch.uint8), 1)
