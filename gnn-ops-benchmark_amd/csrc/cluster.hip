@@ -191,6 +191,49 @@ __global__ void random_walk_kernel(const int64_t* __restrict__ rowptr, const int
     }
 }
 
+// ---- graclus_cluster: greedy pairing of every node with one unmatched neighbour (the heaviest edge when weights are given) ----
+// The package walks the nodes in a random order, sequentially. The parallel form is handshake matching: every unmatched node
+// proposes along its best still-available edge; an edge whose two ends propose to each other is matched. "Best" is a total
+// order on edges — (weight, a seeded hash of the unordered pair) — identical from both ends, so the best available edge of
+// the whole graph is always mutual: every round matches at least one pair and the result is a maximal matching, random
+// through the seed exactly as the package's is through its permutation. cluster[n] = min(n, partner), or n when alone.
+__device__ inline uint32_t pair_hash(int64_t a, int64_t b, uint64_t seed) {
+    const uint64_t lo = (uint64_t)(a < b ? a : b), hi = (uint64_t)(a < b ? b : a);
+    return mix32(seed ^ (lo * 0x9e3779b97f4a7c15ull + hi));
+}
+
+template <typename T>
+__global__ void graclus_propose_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col, const T* __restrict__ weight,
+                                       int64_t N, uint64_t seed, const int64_t* __restrict__ cluster, int64_t* __restrict__ proposal,
+                                       int* __restrict__ active) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        int64_t best = -1;
+        if (cluster[n] < 0) {
+            float bw = -__builtin_huge_valf();
+            uint32_t bh = 0;
+            for (int64_t e = rowptr[n]; e < rowptr[n + 1]; ++e) {
+                const int64_t v = col[e];
+                if (v == n || cluster[v] >= 0) continue;
+                const float w = weight ? Elem<T>::load(weight + e) : 0.f;
+                const uint32_t h = pair_hash(n, v, seed);
+                if (best < 0 || w > bw || (w == bw && (h > bh || (h == bh && v < best)))) { best = v; bw = w; bh = h; }
+            }
+            if (best >= 0) atomicAdd(active, 1);
+        }
+        proposal[n] = best;
+    }
+}
+__global__ void graclus_match_kernel(int64_t N, const int64_t* __restrict__ proposal, int64_t* __restrict__ cluster) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = proposal[n];
+        if (v >= 0 && proposal[v] == n) cluster[n] = n < v ? n : v;   // both ends write the same id to their own slot
+    }
+}
+__global__ void graclus_finish_kernel(int64_t N, int64_t* __restrict__ cluster) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+        if (cluster[n] < 0) cluster[n] = n;
+}
+
 }  // namespace
 
 #define GNNOPS_BY_DTYPE(dtype, CALL, what)                                   \
@@ -258,4 +301,24 @@ extern "C" int gnnops_random_walk(const int64_t* rowptr, const int64_t* col, con
     const int grid = gnnops_grid_cap(gnnops_cdiv(walkers, 256));
     hipLaunchKernelGGL(random_walk_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, rowptr, col, start, walkers, walk_length, seed, out);
     return gnnops_check_launch("random_walk");
+}
+
+// `rounds` propose + match rounds over a CSR adjacency (int64 rowptr / col, weight in CSR order or NULL). cluster: int64 [N],
+// -1 = unmatched, set by the caller before the first call; d_active (device int) = proposals made in the LAST round run here:
+// 0 means no unmatched node has an unmatched neighbour any more. finish != 0 then gives the nodes left alone their own id.
+extern "C" int gnnops_graclus_rounds(const int64_t* rowptr, const int64_t* col, const void* weight, int64_t N, uint64_t seed, int rounds,
+                                     int64_t* cluster, int64_t* proposal, int* d_active, int finish, int dtype, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(N >= 0 && rounds >= 0, GNNOPS_EINVAL, "graclus: bad shape");
+    if (N == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(rowptr && cluster && proposal && d_active, GNNOPS_EINVAL, "graclus: null pointer");
+    hipStream_t stream = (hipStream_t)s;
+    const int grid = gnnops_grid_cap(gnnops_cdiv(N, 256));
+    for (int r = 0; r < rounds; ++r) {
+        if (hipMemsetAsync(d_active, 0, sizeof(int), stream) != hipSuccess) return gnnops_check_launch("graclus memset");
+        GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((graclus_propose_kernel<T>), dim3(grid), dim3(256), 0, stream, rowptr, col, (const T*)weight, N,
+                                                  seed, cluster, proposal, d_active), "graclus")
+        hipLaunchKernelGGL(graclus_match_kernel, dim3(grid), dim3(256), 0, stream, N, proposal, cluster);
+    }
+    if (finish) hipLaunchKernelGGL(graclus_finish_kernel, dim3(grid), dim3(256), 0, stream, N, cluster);
+    return gnnops_check_launch("graclus");
 }

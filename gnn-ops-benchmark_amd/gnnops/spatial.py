@@ -294,3 +294,44 @@ def random_walk(row, col, start, walk_length, p=1.0, q=1.0, coalesced=True, num_
         check(_lib.load().gnnops_random_walk(rowptr.data_ptr(), colc.data_ptr(), start.data_ptr(), start.numel(), int(walk_length), int(seed),
                                              out.data_ptr(), _stream()), "random_walk")
     return out
+
+
+def graclus_cluster(row, col, weight=None, num_nodes=None, seed=None):
+    """torch_cluster.graclus_cluster(row, col, weight=None, num_nodes=None) (ops.txt:35): pairs every node with one unmatched
+    neighbour (the heaviest edge when weights are given); cluster[n] = min(n, partner), or n for a node left alone. The
+    package's result depends on a random node order; here on ``seed`` (extra argument; default from torch's RNG) through a
+    hash that breaks ties between equally heavy edges. Rounds run eight at a time between read-backs of one counter."""
+    _require_gpu(row, col, weight)
+    if num_nodes is None:
+        num_nodes = int(max(row.max(), col.max())) + 1 if row.numel() else 0
+    dev = row.device
+    cluster = torch.full((num_nodes,), -1, dtype=torch.int64, device=dev)
+    if num_nodes == 0:
+        return cluster
+    dt = _dtype_code(weight, "graclus_cluster") if weight is not None else 0
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
+    w_csr = None
+    if row.numel():
+        plan = ops.Plan(row.contiguous(), num_nodes, col.contiguous())
+        rowptr = plan.rowptr.to(torch.int64)
+        order = plan.perm[: row.numel()].long()
+        col = plan.col if plan.col is not None else col[order]
+        if weight is not None:
+            w_csr = weight.contiguous()[order].contiguous()
+    colc = col.contiguous() if col.numel() else torch.zeros(1, dtype=torch.int64, device=dev)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    proposal = torch.empty(num_nodes, dtype=torch.int64, device=dev)
+    active = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = _lib.load()
+    while True:
+        with torch.cuda.device(dev):
+            check(L.gnnops_graclus_rounds(rowptr.data_ptr(), colc.data_ptr(), w_csr.data_ptr() if w_csr is not None else None, num_nodes,
+                                          int(seed), 8, cluster.data_ptr(), proposal.data_ptr(), active.data_ptr(), 0, dt, _stream()),
+                  "graclus_cluster")
+        if int(active) == 0:
+            break
+    with torch.cuda.device(dev):
+        check(L.gnnops_graclus_rounds(rowptr.data_ptr(), colc.data_ptr(), None, num_nodes, int(seed), 0, cluster.data_ptr(),
+                                      proposal.data_ptr(), active.data_ptr(), 1, dt, _stream()), "graclus_cluster")
+    return cluster

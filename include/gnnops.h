@@ -408,6 +408,10 @@ int gnnops_edge_reduce(int functor, const void* q, int64_t ldq, const void* p, i
  *   gnnops_fps           farthest point sampling per batch: out[out_ptr[b] .. out_ptr[b+1]) starting from start[b];
  *                        dist_workspace float [N]
  *   gnnops_random_walk   out [walkers, walk_length + 1]: uniform next neighbour over a CSR adjacency (int64 rowptr, col)
+ *   gnnops_graclus_rounds  `rounds` rounds of handshake matching over a CSR adjacency (weight in CSR order or NULL): cluster
+ *                        int64 [N] (-1 = unmatched, initialised by the caller) gets min(n, partner) for matched pairs;
+ *                        *d_active (device int) = proposals in the last round (0: the matching is maximal); finish != 0
+ *                        gives every node still alone its own id. proposal: int64 [N] scratch.
  * ------------------------------------------------------------------------------------------- */
 int gnnops_spline_basis(const void* pseudo, const int64_t* kernel_size, const uint8_t* is_open_spline, int64_t E, int D,
                         int degree, void* basis, int64_t* weight_index, int dtype, gnnops_stream_t stream);
@@ -427,6 +431,8 @@ int gnnops_fps(const void* x, const int64_t* ptr, const int64_t* out_ptr, const 
                float* dist_workspace, int64_t* out, int dtype, gnnops_stream_t stream);
 int gnnops_random_walk(const int64_t* rowptr, const int64_t* col, const int64_t* start, int64_t walkers, int walk_length,
                        uint64_t seed, int64_t* out, gnnops_stream_t stream);
+int gnnops_graclus_rounds(const int64_t* rowptr, const int64_t* col, const void* weight, int64_t N, uint64_t seed, int rounds,
+                          int64_t* cluster, int64_t* proposal, int* d_active, int finish, int dtype, gnnops_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -207,6 +207,41 @@ def test_random_walk_properties():
         random_walk(row.cuda(), col.cuda(), start.cuda(), 3, p=2.0)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_graclus_cluster_is_a_maximal_matching(weighted):
+    """Random by nature (the package shuffles the nodes): the result must be a MAXIMAL matching of the graph — every cluster is
+    a node alone or two adjacent nodes named by the smaller id, and no two nodes left alone are adjacent — reproducible per
+    seed; with weights, a node's partner is never lighter than an edge to a node that was left alone."""
+    from torch_cluster import graclus_cluster
+
+    g = torch.Generator().manual_seed(11)
+    n, e = 500, 1800
+    a, b = torch.randint(0, n - 3, (e,), generator=g), torch.randint(0, n - 3, (e,), generator=g)   # the last 3 nodes are isolated
+    row, col = torch.cat([a, b]), torch.cat([b, a])                                                   # symmetric, with some self loops
+    w = torch.rand(e, generator=g)
+    weight = torch.cat([w, w]) if weighted else None
+    cl = graclus_cluster(row.cuda(), col.cuda(), None if weight is None else weight.cuda(), n, seed=3).cpu()
+    assert cl.shape == (n,) and bool((cl <= torch.arange(n)).all())
+    sizes = torch.bincount(cl, minlength=n)
+    assert int(sizes.max()) <= 2 and bool((cl[cl] == cl).all())
+    adj = torch.zeros(n, n, dtype=torch.bool)
+    adj[row, col] = True
+    adj.fill_diagonal_(False)
+    pairs = torch.nonzero(cl != torch.arange(n)).view(-1)
+    assert bool(adj[pairs, cl[pairs]].all()), "partners must be neighbours"
+    single = sizes[cl] == 1
+    assert not bool(adj[single][:, single].any()), "two adjacent nodes were both left alone: the matching is not maximal"
+    assert torch.equal(cl[-3:], torch.arange(n - 3, n))
+    assert torch.equal(cl, graclus_cluster(row.cuda(), col.cuda(), None if weight is None else weight.cuda(), n, seed=3).cpu())
+    if not weighted:
+        assert not torch.equal(cl, graclus_cluster(row.cuda(), col.cuda(), None, n, seed=4).cpu())
+    # known answer with weights: path 0 -1- 1 -5- 2 -1- 3: the heavy middle edge is taken, the ends stay alone
+    r = torch.tensor([0, 1, 1, 2, 2, 3]).cuda()
+    c = torch.tensor([1, 0, 2, 1, 3, 2]).cuda()
+    ww = torch.tensor([1.0, 1.0, 5.0, 5.0, 1.0, 1.0]).cuda()
+    assert graclus_cluster(r, c, ww, 4, seed=0).cpu().tolist() == [0, 1, 1, 3]
+
+
 def test_spatial_ops_refuse_cpu_tensors():
     from torch_cluster import knn
     from torch_spline_conv import spline_basis
