@@ -101,7 +101,7 @@ class _Packed:
     stacked  (stack=True) : [h_0 | h_1 | ...] @ [W_0^T ; W_1^T ; ...] — several inputs summed into one output"""
 
     def __init__(self):
-        self.key = self.weight = self.bias = None
+        self.key = self.weight = self.bias = self._alive = None
 
     def get(self, params, blocks, stack=False):
         """params: the Parameters the blocks are cut from; blocks: [(weight or a column slice of it [out, in], bias or None)]."""
@@ -120,6 +120,7 @@ class _Packed:
                     else:
                         self.bias = None
             self.key = key
+            self._alive = list(params)   # the key holds ids: keep the tensors they name alive so that no id is handed out again
         return self.weight, self.bias
 
 

@@ -5,7 +5,7 @@ knn_graph, radius, radius_graph, nearest, random_walk}. The import seams are the
 output of it is in the reference tree): oracle/spatial_oracle.py restates the published definitions.
 
 Forward only. Device tensors only — CPU tensors are refused, not emulated."""
-import math
+import weakref
 
 import torch
 
@@ -18,22 +18,23 @@ from .sparse import _csr_arrays
 # ---------------------------------------------------------------------------------------------------------------------
 # torch_spline_conv
 # ---------------------------------------------------------------------------------------------------------------------
-_host_cache = {}   # id(tensor) -> (weakref-free key, host copy): kernel_size / is_open_spline are tiny and constant per layer
+_host_cache = {}   # id(tensor) -> (weakref to it, version, host copy): kernel_size / is_open_spline are tiny and constant per layer
 
 
 def _host(t, dtype):
     """kernel_size / is_open_spline as host arrays (the C entry points read them while launching). A device tensor is read
-    back once per (tensor object, version) — one synchronisation when a layer is first used, none afterwards."""
+    back once per tensor OBJECT and version — one synchronisation when a layer is first used, none afterwards. The weak
+    reference is what makes the entry safe: an id (and a data pointer) can be handed to a new tensor once the old one died."""
     if t.device.type == "cpu":
         return t.to(dtype).contiguous()
-    key = (id(t), t._version, t.data_ptr())
     hit = _host_cache.get(id(t))
-    if hit is None or hit[0] != key:
-        if len(_host_cache) > 64:
-            _host_cache.clear()
-        hit = (key, t.detach().to("cpu", dtype).contiguous())
-        _host_cache[id(t)] = hit
-    return hit[1]
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    host = t.detach().to("cpu", dtype).contiguous()
+    if not t.is_inference():
+        key = id(t)
+        _host_cache[key] = (weakref.ref(t, lambda _r, key=key: _host_cache.pop(key, None)), t._version, host)
+    return host
 
 
 def spline_basis(pseudo, kernel_size, is_open_spline, degree):
