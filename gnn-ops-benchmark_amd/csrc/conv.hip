@@ -39,7 +39,16 @@ struct Args {
     float avg_log, avg_lin;
     int gshift, kchunks;
     int nt;   // gathered table does not fit the Infinity Cache: stream it past (nontemporal 16-B loads)
+    // heavy destinations ("hubs": more than T_HUB edges) — set aside by the main kernel, reduced piecewise afterwards
+    unsigned int* hub_count;   // [0] hubs found, [1] pieces in all
+    int32_t* hub_rows;         // [max_hubs] destination ids
+    int32_t* piece_base;       // [max_hubs + 1] first piece of each hub
+    float* partial;            // [pieces][accs][K] fp32 partial accumulators (accs = 4 for MULTI, else 1)
+    int max_hubs;
 };
+
+constexpr int T_HUB = 8192;    // as csrc/hub.h: a destination with more edges than this is not left to one lane group
+constexpr int PIECE = 2048;    // edges per piece of a hub
 
 template <int F> struct Parts;   // K-wide parts per row of q / p / w
 template <> struct Parts<F_COPY> { static constexpr int Q = 1, P = 0, W = 0; };
@@ -130,24 +139,132 @@ __device__ inline void message(const float (*pv)[VEC], const float (*qv)[VEC], c
 // that rows of different degree do not share a wave: with 16-B lanes four rows of K = 128 fp16 share one, the wave runs
 // for its longest row (~7.7 edges at a mean of 5) and half the issued messages are masked off. Plain copies / adds keep
 // the 16-B lanes (fewest memory instructions; they are bandwidth-bound).
+// the edges [jb, je) of destination n folded into the running accumulators (columns c0 .. c0 + VEC of every part)
 template <typename T, int F, bool MULTI, bool HAS_W, int VEC, bool WAVE_ROW>
-__global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
+__device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int32_t je, float* sum, float* sq, float* mn, float* mx) {
     constexpr int U = Parts<F>::Q == 2 ? 4 : 8;
     constexpr int NQ = Parts<F>::Q, NP = Parts<F>::P > 0 ? Parts<F>::P : 1, NW = Parts<F>::W > 0 ? Parts<F>::W : 1;
     const T* __restrict__ q = (const T*)a.q;
     const T* __restrict__ p = (const T*)a.p;
     const T* __restrict__ w = (const T*)a.w;
-    const T* __restrict__ add = (const T*)a.add;
-    const int32_t* __restrict__ rowptr = a.rowptr;
     const int32_t* __restrict__ perm = a.perm;
     const int64_t* __restrict__ col = a.col;
-    T* __restrict__ out = (T*)a.out;
+    const int K = (int)a.K, ldq = (int)a.ldq, ldw = (int)a.ldw;   // < 2^31 (host-checked): row offsets are one 32 x 32 -> 64 multiply
+    float pv[NP][VEC];
+    if constexpr (Parts<F>::P > 0) {
+#pragma unroll
+        for (int r = 0; r < NP; ++r) load_vec<T, VEC>(p + (int64_t)n * a.ldp + r * K + c0, pv[r]);
+    }
+    for (int32_t j = jb; j < je; j += U) {
+        int c[U], e[U];
+        u32x4 qr[U][NQ], wr[U][NW];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {       // all the step's edge ids first ...
+            c[u] = 0;
+            e[u] = 0;
+            if (j + u < je) {
+                c[u] = (int)col[j + u];
+                if constexpr (HAS_W) e[u] = perm ? perm[j + u] : j + u;
+                if constexpr (WAVE_ROW) { c[u] = __builtin_amdgcn_readfirstlane(c[u]); e[u] = __builtin_amdgcn_readfirstlane(e[u]); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {       // ... then all its row loads in flight together (raw words: no conversion here)
+            if (j + u < je) {
+#pragma unroll
+                for (int r = 0; r < NQ; ++r) qr[u][r] = load_raw<T, VEC>(q + (int64_t)c[u] * ldq + r * K + c0, a.nt != 0);
+                if constexpr (HAS_W) {
+#pragma unroll
+                    for (int r = 0; r < NW; ++r) wr[u][r] = load_raw<T, VEC>(w + (int64_t)e[u] * ldw + r * K + c0, true);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j + u < je) {   // skipped outright once every row of the wave is past its end
+                float qv[NQ][VEC], wv[NW][VEC], m[VEC];
+#pragma unroll
+                for (int r = 0; r < NQ; ++r) unpack_vec<T, VEC>(qr[u][r], qv[r]);
+                if constexpr (HAS_W) {
+#pragma unroll
+                    for (int r = 0; r < NW; ++r) unpack_vec<T, VEC>(wr[u][r], wv[r]);
+                }
+                message<F, HAS_W, VEC>(pv, qv, wv, m);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    sum[v] += m[v];
+                    if constexpr (MULTI) {
+                        sq[v] += m[v] * m[v];
+                        mn[v] = fminf(mn[v], m[v]);
+                        mx[v] = fmaxf(mx[v], m[v]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// accumulators of a whole destination -> its output blocks: aggregators x degree scalers (+ the residual row)
+template <typename T, int VEC>
+__device__ inline void finish_row(const Args& a, int n, int c0, int32_t cnt, const float* sum, const float* sq, const float* mn,
+                                  const float* mx) {
+    const T* __restrict__ add = (const T*)a.add;
+    const int K = (int)a.K;
+    const float degc = (float)(cnt < 1 ? 1 : cnt);
+    const float logd = __logf(degc + 1.f);
+    T* orow = (T*)a.out + (int64_t)n * a.ldo + c0;
+    for (int s = 0; s < a.n_scal; ++s) {
+        float scale = 1.f;
+        switch (a.scal[s]) {
+            case S_AMPLIFICATION: scale = logd / a.avg_log; break;
+            case S_ATTENUATION: scale = a.avg_log / logd; break;
+            case S_LINEAR: scale = degc / a.avg_lin; break;
+            case S_INVERSE_LINEAR: scale = a.avg_lin / degc; break;
+            default: break;
+        }
+        for (int g = 0; g < a.n_aggr; ++g) {
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float r;
+                switch (a.aggr[g]) {
+                    case A_SUM: r = sum[v]; break;
+                    case A_MEAN: r = sum[v] / degc; break;
+                    case A_MIN: r = cnt > 0 ? mn[v] : 0.f; break;
+                    case A_MAX: r = cnt > 0 ? mx[v] : 0.f; break;
+                    default: {   // A_STD: sqrt(relu(mean(m^2) - mean(m)^2) + 1e-5), PNAConv.aggregate
+                        const float mean = sum[v] / degc;
+                        r = __fsqrt_rn(fmaxf(sq[v] / degc - mean * mean, 0.f) + 1e-5f);
+                    }
+                }
+                o[v] = r * scale;
+            }
+            if (add && s == 0 && g == 0) {
+                float t[VEC];
+                load_vec<T, VEC>(add + (int64_t)n * a.ldadd + c0, t);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o[v] += t[v];
+            }
+            store_vec<T, VEC>(orow + (int64_t)(s * a.n_aggr + g) * K, o);
+        }
+    }
+}
+
+template <int VEC>
+__device__ inline void reset(float* sum, float* sq, float* mn, float* mx) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { sum[v] = 0.f; sq[v] = 0.f; mn[v] = __builtin_huge_valf(); mx[v] = -__builtin_huge_valf(); }
+}
+
+template <typename T, int F, bool MULTI, bool HAS_W, int VEC, bool WAVE_ROW>
+__global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
+    const int32_t* __restrict__ rowptr = a.rowptr;
     const int G = 1 << a.gshift;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> a.gshift;
     const int gl = (int)(gtid & (G - 1));
     const int64_t items = (int64_t)a.kchunks * a.N;
-    const int K = (int)a.K, ldq = (int)a.ldq, ldw = (int)a.ldw;   // < 2^31 (host-checked): row offsets are one 32 x 32 -> 64 multiply
+    const int K = (int)a.K;
 
     for (int64_t item = gtid >> a.gshift; item < items; item += ngroups) {
         int n, chunk;
@@ -163,103 +280,102 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
             beg = __builtin_amdgcn_readfirstlane(beg);
             end = __builtin_amdgcn_readfirstlane(end);
         }
-
-        float pv[NP][VEC];
-        if constexpr (Parts<F>::P > 0) {
-#pragma unroll
-            for (int r = 0; r < NP; ++r) load_vec<T, VEC>(p + (int64_t)n * a.ldp + r * K + c0, pv[r]);
+        if (a.hub_count && end - beg > T_HUB) {   // a hub: set aside for the piecewise pass, neither reduced nor stored here
+            if (gl == 0 && chunk == 0) {
+                const unsigned int slot = atomicAdd(a.hub_count, 1u);
+                if ((int)slot < a.max_hubs) a.hub_rows[slot] = n;
+            }
+            continue;
         }
         float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) { sum[v] = 0.f; sq[v] = 0.f; mn[v] = __builtin_huge_valf(); mx[v] = -__builtin_huge_valf(); }
+        reset<VEC>(sum, sq, mn, mx);
+        accumulate<T, F, MULTI, HAS_W, VEC, WAVE_ROW>(a, n, c0, beg, end, sum, sq, mn, mx);
+        finish_row<T, VEC>(a, n, c0, end - beg, sum, sq, mn, mx);
+    }
+}
 
-        for (int32_t j = beg; j < end; j += U) {
-            int c[U], e[U];
-            u32x4 qr[U][NQ], wr[U][NW];
+// ---- hubs: pieces of PIECE edges reduced by separate lane groups into fp32 partials, combined in piece order ----
+__global__ void hub_pieces_kernel(const Args a) {   // one thread: first piece of every hub (there are at most E / T_HUB of them)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned int hubs = a.hub_count[0];
+    if ((int)hubs > a.max_hubs) hubs = (unsigned)a.max_hubs;
+    int32_t base = 0;
+    for (unsigned int h = 0; h < hubs; ++h) {
+        a.piece_base[h] = base;
+        const int n = a.hub_rows[h];
+        base += (a.rowptr[n + 1] - a.rowptr[n] + PIECE - 1) / PIECE;
+    }
+    a.piece_base[hubs] = base;
+    a.hub_count[1] = (unsigned int)base;
+}
+
+template <typename T, int F, bool MULTI, bool HAS_W, int VEC, bool WAVE_ROW>
+__global__ __launch_bounds__(256) void hub_partial_kernel(const Args a) {
+    constexpr int ACCS = MULTI ? 4 : 1;
+    const int G = 1 << a.gshift;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> a.gshift;
+    const int gl = (int)(gtid & (G - 1));
+    const int hubs = min((int)a.hub_count[0], a.max_hubs);
+    const int64_t items = (int64_t)a.hub_count[1] * a.kchunks;
+    const int K = (int)a.K;
+    for (int64_t item = gtid >> a.gshift; item < items; item += ngroups) {
+        int piece = (int)(item / a.kchunks), chunk = (int)(item % a.kchunks);
+        if constexpr (WAVE_ROW) {
+            piece = __builtin_amdgcn_readfirstlane(piece);
+            chunk = __builtin_amdgcn_readfirstlane(chunk);
+        }
+        int lo = 0, hi = hubs;   // hub h with piece_base[h] <= piece < piece_base[h + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.piece_base[mid] <= piece) lo = mid; else hi = mid;
+        }
+        const int n = a.hub_rows[lo];
+        const int c0 = (chunk * G + gl) * VEC;
+        if (c0 >= K) continue;
+        int32_t jb = a.rowptr[n] + (piece - a.piece_base[lo]) * PIECE;
+        int32_t je = min(jb + PIECE, a.rowptr[n + 1]);
+        if constexpr (WAVE_ROW) {
+            jb = __builtin_amdgcn_readfirstlane(jb);
+            je = __builtin_amdgcn_readfirstlane(je);
+        }
+        float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
+        reset<VEC>(sum, sq, mn, mx);
+        accumulate<T, F, MULTI, HAS_W, VEC, WAVE_ROW>(a, n, c0, jb, je, sum, sq, mn, mx);
+        float* pp = a.partial + (int64_t)piece * ACCS * K + c0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {       // all the step's edge ids first ...
-                c[u] = 0;
-                e[u] = 0;
-                if (j + u < end) {
-                    c[u] = (int)col[j + u];
-                    if constexpr (HAS_W) e[u] = perm ? perm[j + u] : j + u;
-                    if constexpr (WAVE_ROW) { c[u] = __builtin_amdgcn_readfirstlane(c[u]); e[u] = __builtin_amdgcn_readfirstlane(e[u]); }
-                }
-            }
+        for (int v = 0; v < VEC; ++v) {
+            pp[v] = sum[v];
+            if constexpr (MULTI) { pp[K + v] = sq[v]; pp[2 * K + v] = mn[v]; pp[3 * K + v] = mx[v]; }
+        }
+    }
+}
+
+template <typename T, bool MULTI, int VEC>
+__global__ __launch_bounds__(256) void hub_finish_kernel(const Args a) {
+    constexpr int ACCS = MULTI ? 4 : 1;
+    const int G = 1 << a.gshift;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> a.gshift;
+    const int gl = (int)(gtid & (G - 1));
+    const int hubs = min((int)a.hub_count[0], a.max_hubs);
+    const int K = (int)a.K;
+    for (int64_t item = gtid >> a.gshift; item < (int64_t)hubs * a.kchunks; item += ngroups) {
+        const int h = (int)(item / a.kchunks), chunk = (int)(item % a.kchunks);
+        const int c0 = (chunk * G + gl) * VEC;
+        if (c0 >= K) continue;
+        const int n = a.hub_rows[h];
+        float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
+        reset<VEC>(sum, sq, mn, mx);
+        for (int piece = a.piece_base[h]; piece < a.piece_base[h + 1]; ++piece) {   // in piece order: the same result every run
+            const float* pp = a.partial + (int64_t)piece * ACCS * K + c0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {       // ... then all its row loads in flight together (raw words: no conversion here)
-                if (j + u < end) {
-#pragma unroll
-                    for (int r = 0; r < NQ; ++r) qr[u][r] = load_raw<T, VEC>(q + (int64_t)c[u] * ldq + r * K + c0, a.nt != 0);
-                    if constexpr (HAS_W) {
-#pragma unroll
-                        for (int r = 0; r < NW; ++r) wr[u][r] = load_raw<T, VEC>(w + (int64_t)e[u] * ldw + r * K + c0, true);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (j + u < end) {   // skipped outright once every row of the wave is past its end
-                    float qv[NQ][VEC], wv[NW][VEC], m[VEC];
-#pragma unroll
-                    for (int r = 0; r < NQ; ++r) unpack_vec<T, VEC>(qr[u][r], qv[r]);
-                    if constexpr (HAS_W) {
-#pragma unroll
-                        for (int r = 0; r < NW; ++r) unpack_vec<T, VEC>(wr[u][r], wv[r]);
-                    }
-                    message<F, HAS_W, VEC>(pv, qv, wv, m);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        sum[v] += m[v];
-                        if constexpr (MULTI) {
-                            sq[v] += m[v] * m[v];
-                            mn[v] = fminf(mn[v], m[v]);
-                            mx[v] = fmaxf(mx[v], m[v]);
-                        }
-                    }
-                }
+            for (int v = 0; v < VEC; ++v) {
+                sum[v] += pp[v];
+                if constexpr (MULTI) { sq[v] += pp[K + v]; mn[v] = fminf(mn[v], pp[2 * K + v]); mx[v] = fmaxf(mx[v], pp[3 * K + v]); }
             }
         }
-
-        const int32_t cnt = end - beg;
-        const float degc = (float)(cnt < 1 ? 1 : cnt);
-        const float logd = __logf(degc + 1.f);
-        T* orow = out + (int64_t)n * a.ldo + c0;
-        for (int s = 0; s < a.n_scal; ++s) {
-            float scale = 1.f;
-            switch (a.scal[s]) {
-                case S_AMPLIFICATION: scale = logd / a.avg_log; break;
-                case S_ATTENUATION: scale = a.avg_log / logd; break;
-                case S_LINEAR: scale = degc / a.avg_lin; break;
-                case S_INVERSE_LINEAR: scale = a.avg_lin / degc; break;
-                default: break;
-            }
-            for (int g = 0; g < a.n_aggr; ++g) {
-                float o[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    float r;
-                    switch (a.aggr[g]) {
-                        case A_SUM: r = sum[v]; break;
-                        case A_MEAN: r = sum[v] / degc; break;
-                        case A_MIN: r = cnt > 0 ? mn[v] : 0.f; break;
-                        case A_MAX: r = cnt > 0 ? mx[v] : 0.f; break;
-                        default: {   // A_STD: sqrt(relu(mean(m^2) - mean(m)^2) + 1e-5), PNAConv.aggregate
-                            const float mean = sum[v] / degc;
-                            r = __fsqrt_rn(fmaxf(sq[v] / degc - mean * mean, 0.f) + 1e-5f);
-                        }
-                    }
-                    o[v] = r * scale;
-                }
-                if (add && s == 0 && g == 0) {
-                    float t[VEC];
-                    load_vec<T, VEC>(add + (int64_t)n * a.ldadd + c0, t);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) o[v] += t[v];
-                }
-                store_vec<T, VEC>(orow + (int64_t)(s * a.n_aggr + g) * K, o);
-            }
-        }
+        finish_row<T, VEC>(a, n, c0, a.rowptr[n + 1] - a.rowptr[n], sum, sq, mn, mx);
     }
 }
 
@@ -274,8 +390,16 @@ int launch_vec(Args& a, hipStream_t stream) {
     a.kchunks = (int)gnnops_cdiv(lanes, (int64_t)1 << gshift);
     const int64_t items = (int64_t)a.kchunks * a.N;
     const int grid = gnnops_grid_cap(gnnops_cdiv(items, 256 >> gshift), 256 * 64);
+    if (a.hub_count && hipMemsetAsync(a.hub_count, 0, 8, stream) != hipSuccess) return gnnops_check_launch("edge_reduce hub memset");
     if (gshift == 6) hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, HAS_W, VEC, true>), dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, HAS_W, VEC, false>), dim3(grid), dim3(256), 0, stream, a);
+    if (a.hub_count) {   // the hub passes find their own work on the device (counts are never read back); empty when there is no hub
+        hipLaunchKernelGGL(hub_pieces_kernel, dim3(1), dim3(64), 0, stream, a);
+        const int hgrid = 256 * 8;
+        if (gshift == 6) hipLaunchKernelGGL((hub_partial_kernel<T, F, MULTI, HAS_W, VEC, true>), dim3(hgrid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((hub_partial_kernel<T, F, MULTI, HAS_W, VEC, false>), dim3(hgrid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((hub_finish_kernel<T, MULTI, VEC>), dim3(256), dim3(256), 0, stream, a);
+    }
     return gnnops_check_launch("edge_reduce");
 }
 
@@ -317,11 +441,43 @@ int dispatch(int functor, bool multi, const Args& a, int max_vec, hipStream_t st
 
 }  // namespace
 
+namespace {
+struct HubLayout { size_t counters, rows, base, partial, total; int max_hubs; };
+inline HubLayout hub_layout(int64_t E, int64_t K) {
+    HubLayout l{};
+    l.max_hubs = (int)(E / T_HUB) + 1;
+    const size_t pieces = (size_t)(E / PIECE) + (size_t)l.max_hubs;   // sum over hubs of ceil(deg / PIECE)
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    l.counters = 0;
+    l.rows = 256;
+    l.base = l.rows + up((size_t)l.max_hubs * 4);
+    l.partial = l.base + up(((size_t)l.max_hubs + 1) * 4);
+    l.total = l.partial + pieces * 4 * (size_t)K * 4;
+    return l;
+}
+}  // namespace
+
+extern "C" size_t gnnops_edge_reduce_hub_workspace_bytes(int64_t E, int64_t K) {
+    // below 32768 edges a hub costs one wave at most ~1.5 ms, while the three (empty) hub launches would cost every
+    // launch-bound layer call on a batch of small graphs ~12 us
+    if (E <= 4 * T_HUB || K <= 0) return 0;
+    return hub_layout(E, K).total;
+}
+
 extern "C" int gnnops_edge_reduce(int functor, const void* q, int64_t ldq, const void* p, int64_t ldp, const void* w, int64_t ldw,
                                   const void* add, int64_t ldadd, const int32_t* rowptr, const int32_t* perm, const int64_t* col,
                                   void* out, int64_t ldo, int64_t N, int64_t E, int64_t K, const int* aggr, int n_aggr,
                                   const int* scalers, int n_scalers, float avg_deg_log, float avg_deg_lin, int dtype,
                                   gnnops_stream_t s) {
+    return gnnops_edge_reduce_hubs(functor, q, ldq, p, ldp, w, ldw, add, ldadd, rowptr, perm, col, out, ldo, N, E, K, aggr, n_aggr,
+                                   scalers, n_scalers, avg_deg_log, avg_deg_lin, dtype, nullptr, 0, s);
+}
+
+extern "C" int gnnops_edge_reduce_hubs(int functor, const void* q, int64_t ldq, const void* p, int64_t ldp, const void* w,
+                                       int64_t ldw, const void* add, int64_t ldadd, const int32_t* rowptr, const int32_t* perm,
+                                       const int64_t* col, void* out, int64_t ldo, int64_t N, int64_t E, int64_t K, const int* aggr,
+                                       int n_aggr, const int* scalers, int n_scalers, float avg_deg_log, float avg_deg_lin, int dtype,
+                                       void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t s) {
     GNNOPS_REQUIRE(N >= 0 && E >= 0 && K >= 0, GNNOPS_EINVAL, "edge_reduce: negative size");
     GNNOPS_REQUIRE(N < ((int64_t)1 << 31) && E < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED, "edge_reduce: N and E must be < 2^31");
     GNNOPS_REQUIRE(K < ((int64_t)1 << 24) && ldq < ((int64_t)1 << 31) && ldw < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED,
@@ -372,6 +528,17 @@ extern "C" int gnnops_edge_reduce(int functor, const void* q, int64_t ldq, const
     narrow(q, ldq); narrow(p, ldp); narrow(w, ldw); narrow(add, ldadd); narrow(out, ldo);
     if ((K * es) % (max_vec * es) != 0)
         while (max_vec > 1 && K % max_vec != 0) max_vec >>= 1;
+    if (hub_workspace && E > 4 * T_HUB) {   // destinations with more than T_HUB edges are reduced piecewise (sums re-associated)
+        const HubLayout l = hub_layout(E, K);
+        GNNOPS_REQUIRE(hub_workspace_bytes >= l.total && (uintptr_t)hub_workspace % 16 == 0, GNNOPS_EWORKSPACE,
+                       "edge_reduce: hub workspace %zu < %zu", hub_workspace_bytes, l.total);
+        char* wsp = (char*)hub_workspace;
+        a.hub_count = (unsigned int*)(wsp + l.counters);
+        a.hub_rows = (int32_t*)(wsp + l.rows);
+        a.piece_base = (int32_t*)(wsp + l.base);
+        a.partial = (float*)(wsp + l.partial);
+        a.max_hubs = l.max_hubs;
+    }
     hipStream_t stream = (hipStream_t)s;
     switch (dtype) {
         case GNNOPS_F32: return dispatch<float>(functor, multi, a, max_vec, stream);

@@ -83,11 +83,14 @@ def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=
     c_aggr = (ctypes.c_int * len(aggr_ids))(*aggr_ids)
     c_scal = (ctypes.c_int * max(len(scal_ids), 1))(*scal_ids)
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    L = _lib.load()
+    hub_bytes = L.gnnops_edge_reduce_hub_workspace_bytes(E, K)   # destinations with more than 8192 edges: reduced piecewise
+    hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=q.device) if hub_bytes else None
     with torch.cuda.device(q.device):
-        rc = _lib.load().gnnops_edge_reduce(FUNCTORS[functor], ptr(q), ldq, ptr(p), ldp, ptr(w), ldw, ptr(add), ldadd,
-                                            plan.rowptr.data_ptr(), plan.perm.data_ptr(), col.data_ptr(), out.data_ptr(), ldo,
-                                            num_dst, E, K, c_aggr, len(aggr_ids), c_scal, len(scal_ids), avg_log, avg_lin, dt,
-                                            _stream())
+        rc = L.gnnops_edge_reduce_hubs(FUNCTORS[functor], ptr(q), ldq, ptr(p), ldp, ptr(w), ldw, ptr(add), ldadd,
+                                       plan.rowptr.data_ptr(), plan.perm.data_ptr(), col.data_ptr(), out.data_ptr(), ldo,
+                                       num_dst, E, K, c_aggr, len(aggr_ids), c_scal, len(scal_ids), avg_log, avg_lin, dt,
+                                       ptr(hub_ws), hub_bytes, _stream())
     check(rc, "edge_reduce")
     return out
 

@@ -388,6 +388,15 @@ int gnnops_edge_reduce(int functor, const void* q, int64_t ldq, const void* p, i
                        void* out, int64_t ldo, int64_t N, int64_t E, int64_t K, const int* aggr, int n_aggr,
                        const int* scalers, int n_scalers, float avg_deg_log, float avg_deg_lin, int dtype,
                        gnnops_stream_t stream);
+/* The same with destinations of more than 8192 edges ("hubs", as csrc/hub.h) set aside by the main kernel and reduced in
+ * pieces of 2048 edges by separate lane groups (fp32 partial accumulators, combined in piece order: the same result every
+ * run, sums re-associated for those rows only). hub_workspace = gnnops_edge_reduce_hub_workspace_bytes(E, K) bytes, or NULL. */
+size_t gnnops_edge_reduce_hub_workspace_bytes(int64_t E, int64_t K);
+int gnnops_edge_reduce_hubs(int functor, const void* q, int64_t ldq, const void* p, int64_t ldp, const void* w, int64_t ldw,
+                            const void* add, int64_t ldadd, const int32_t* rowptr, const int32_t* perm, const int64_t* col,
+                            void* out, int64_t ldo, int64_t N, int64_t E, int64_t K, const int* aggr, int n_aggr,
+                            const int* scalers, int n_scalers, float avg_deg_log, float avg_deg_lin, int dtype,
+                            void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The remaining ops of the reference's list (ops.txt:17-19, 29-41) - SURVEY.md 8(f) rank 4. Neither package is in the

@@ -142,6 +142,39 @@ def test_edge_reduce_column_blocks_and_empty(conv):
     assert torch.allclose(got[:, 4 * K:], torch.full((n, K), 1e-5 ** 0.5, device="cuda"))
 
 
+@pytest.mark.parametrize("K,dtype", [(64, torch.float16), (13, torch.float32), (128, torch.float16)])
+def test_edge_reduce_hub_destinations(conv, K, dtype):
+    """Power-law graphs: destinations with more than 8192 edges are set aside and reduced in pieces of 2048 edges (fp32 partial
+    accumulators combined in piece order). A 60 000-edge hub, a 9 000-edge one and one of exactly 8192 (not a hub) among
+    ordinary rows; sum with residual and the full PNA set; cgconv at K = 128 takes the one-row-per-wave form."""
+    n, e = 3000, 200_000
+    g = torch.Generator().manual_seed(K)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    dst[:60_000] = 17
+    dst[60_000:69_000] = 1234
+    dst[dst == 99] = 100
+    dst[69_000:69_000 + 8192] = 99
+    perm = torch.randperm(e, generator=g)
+    ei = torch.stack([src, dst])[:, perm]
+    functor = "cgconv" if K == 128 else "add"
+    nq, npp, nw = conv._PARTS[functor]
+    q = _rand(g, n, nq * K, dtype=dtype)
+    p = _rand(g, n, npp * K, dtype=dtype)
+    add = _rand(g, n, K, dtype=dtype)
+    got = conv.edge_reduce(functor, q.cuda(), ei.cuda(), n, p=p.cuda(), add=add.cuda(), aggr=("sum",))
+    want = _brute(functor, q, p, None, add, ei.numpy(), n, K, ("sum",), (), None)
+    err = np.abs(_f64(got) - want) / np.maximum(np.abs(want), 1.0)          # per element, relative to max(|value|, 1): hubs sum 60 000 terms
+    assert err.max() <= (2e-5 if dtype == torch.float32 else 2e-3), err.max()
+    aggr, scal = ("mean", "min", "max", "std"), ("identity", "amplification", "attenuation")
+    avg = {"log": 3.0, "lin": 60.0}
+    got = conv.edge_reduce(functor, q.cuda(), ei.cuda(), n, p=p.cuda(), aggr=aggr, scalers=scal, avg_deg=avg)
+    want = _brute(functor, q, p, None, None, ei.numpy(), n, K, aggr, scal, avg)
+    _close(got, want, dtype, "hub multi")
+    for row in (17, 1234, 99):
+        _close(got[row:row + 1], want[row:row + 1], dtype, f"row {row}")
+
+
 def test_edge_reduce_refuses_bad_arguments(conv):
     x = torch.rand(10, 8, device="cuda")
     ei = torch.randint(0, 10, (2, 30), device="cuda")
