@@ -297,6 +297,8 @@ def main():
             torch.cuda.empty_cache()
             result["config4"] = config4_leg(torch, gnnops)
             torch.cuda.empty_cache()
+            result["layers"] = layers_leg(torch, gnnops)
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg(D)
     if rank == 0:
@@ -507,6 +509,33 @@ def config4_leg(torch, gnnops):
             "unfused_ms": round(unf, 4), "unfused_alg_GBps": round(alg_u / unf / 1e6, 1),
             "speedup": round(unf / fused, 2),
             "note": "unfused = gnnops.index_select (materialises [E,D]) + torch sum(dtype=float32); fp32 accumulators compared"}
+
+
+def layers_leg(torch, gnnops):
+    """SURVEY 8f rank 4 (side key, not the headline): one CGConv layer (app_bm/groq_script.py:91-109) on a graph of config 2's
+    size — N = 10M nodes, E = 50M edges, 128 channels fp16 — as one dense product + one fused edge pass, and the edge pass
+    alone against its algorithmic bytes."""
+    from gnnops import conv
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(42)
+    n, e, d = 10_000_000, 50_000_000, 128
+    ei = torch.randint(0, n, (2, e), generator=g, device=dev)
+    x = (torch.rand(n, d, generator=g, device=dev) - 0.5).half()
+    torch.manual_seed(0)
+    layer = conv.CGConv(d, 0).half().to(dev)
+    with torch.no_grad():
+        whole = _event_ms(torch, lambda: layer(x, ei), 3)
+        pq = torch.empty(n, 4 * d, dtype=torch.float16, device=dev).normal_(generator=g)
+        edge = _event_ms(torch, lambda: conv.edge_reduce("cgconv", pq[:, 2 * d:], ei, n, p=pq[:, :2 * d], add=x), 3)
+        copy = _event_ms(torch, lambda: conv.edge_reduce("copy", x, ei, n, add=x), 3)
+    alg_edge = e * (2 * d * 2 + 8) + n * (2 * d * 2 + 2 * d * 2) + 4 * (n + 1)
+    alg_copy = e * (d * 2 + 8) + n * (2 * d * 2) + 4 * (n + 1)
+    return {"graph": f"N={n} E={e} uniform endpoints, plan cached", "cgconv128_fp16_layer_ms": round(whole, 4),
+            "cgconv128_fp16_edge_pass": {"ms": round(edge, 4), "alg_GBps": round(alg_edge / edge / 1e6, 1),
+                                         "pct_of_hbm_peak": round(alg_edge / edge / 1e6 / HBM_PEAK_GBS * 100, 2), "bound": "VALU (2 exp, log, rcp per element) + gather"},
+            "gather_sum128_fp16_edge_pass": {"ms": round(copy, 4), "alg_GBps": round(alg_copy / copy / 1e6, 1),
+                                             "pct_of_hbm_peak": round(alg_copy / copy / 1e6 / HBM_PEAK_GBS * 100, 2), "bound": "hbm"}}
 
 
 def cpu_baseline_leg(D):

@@ -155,33 +155,64 @@ __device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int3
 #pragma unroll
         for (int r = 0; r < NP; ++r) load_vec<T, VEC>(p + (int64_t)n * a.ldp + r * K + c0, pv[r]);
     }
-    for (int32_t j = jb; j < je; j += U) {
+    // WAVE_ROW: the ids of up to 64 edges are fetched by ONE coalesced load (lane l holds id l of the run) and handed out
+    // lane by lane — they are wave-uniform there, and U dependent single-id loads per step cost a memory latency each
+    const int lane = threadIdx.x & 63;
+    for (int32_t jrun = jb; jrun < je; jrun += WAVE_ROW ? 64 : (je - jb)) {
+    int cl = 0, el = 0;
+    const int32_t jrun_end = WAVE_ROW ? min(jrun + 64, je) : je;
+    if constexpr (WAVE_ROW) {
+        if (jrun + lane < je) {
+            cl = (int)col[jrun + lane];
+            if constexpr (HAS_W) el = perm ? perm[jrun + lane] : jrun + lane;
+        }
+    }
+    for (int32_t j = jrun; j < jrun_end; j += U) {
         int c[U], e[U];
+        int64_t qrow[U], wrow[U];
         u32x4 qr[U][NQ], wr[U][NW];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {       // all the step's edge ids first ...
-            c[u] = 0;
-            e[u] = 0;
-            if (j + u < je) {
-                c[u] = (int)col[j + u];
-                if constexpr (HAS_W) e[u] = perm ? perm[j + u] : j + u;
-                if constexpr (WAVE_ROW) { c[u] = __builtin_amdgcn_readfirstlane(c[u]); e[u] = __builtin_amdgcn_readfirstlane(e[u]); }
+        for (int u = 0; u < U; ++u) { c[u] = 0; e[u] = 0; }
+        if constexpr (WAVE_ROW) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c[u] = __builtin_amdgcn_readlane(cl, (j - jrun + u) & 63);
+                if constexpr (HAS_W) e[u] = __builtin_amdgcn_readlane(el, (j - jrun + u) & 63);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {       // all the step's edge ids first ...
+                if (j + u < jrun_end) {
+                    c[u] = (int)col[j + u];
+                    if constexpr (HAS_W) e[u] = perm ? perm[j + u] : j + u;
+                }
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {       // ... then all its row loads in flight together (raw words: no conversion here)
-            if (j + u < je) {
+        for (int u = 0; u < U; ++u) {       // ... their row addresses: every wait for an id happens HERE, because ...
+            qrow[u] = (int64_t)c[u] * ldq + c0;      // element offsets, not pointers: a pointer through asm loses its address space
+            if constexpr (HAS_W) wrow[u] = (int64_t)e[u] * ldw + c0;
+            // ... the empty volatile statements pin the address arithmetic to this spot. Left alone, the compiler sinks each
+            // address into the guarded block of its row load, and the wait for id u lands between two row loads — where it
+            // also waits for every row already in flight (vmcnt counts in order): a vmcnt(0) before every row load in one
+            // build of this loop (gather-sum 3.5 -> 4.0 ms, cgconv 8.9 -> 10.7 ms at N = 10M, E = 50M).
+            asm volatile("" : "+v"(qrow[u]));
+            if constexpr (HAS_W) asm volatile("" : "+v"(wrow[u]));
+        }
 #pragma unroll
-                for (int r = 0; r < NQ; ++r) qr[u][r] = load_raw<T, VEC>(q + (int64_t)c[u] * ldq + r * K + c0, a.nt != 0);
+        for (int u = 0; u < U; ++u) {       // ... then all its row loads in flight together (raw words: no conversion here)
+            if (j + u < jrun_end) {
+#pragma unroll
+                for (int r = 0; r < NQ; ++r) qr[u][r] = load_raw<T, VEC>(q + qrow[u] + r * K, a.nt != 0);
                 if constexpr (HAS_W) {
 #pragma unroll
-                    for (int r = 0; r < NW; ++r) wr[u][r] = load_raw<T, VEC>(w + (int64_t)e[u] * ldw + r * K + c0, true);
+                    for (int r = 0; r < NW; ++r) wr[u][r] = load_raw<T, VEC>(w + wrow[u] + r * K, true);
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (j + u < je) {   // skipped outright once every row of the wave is past its end
+            if (j + u < jrun_end) {   // skipped outright once every row of the wave is past its end
                 float qv[NQ][VEC], wv[NW][VEC], m[VEC];
 #pragma unroll
                 for (int r = 0; r < NQ; ++r) unpack_vec<T, VEC>(qr[u][r], qv[r]);
@@ -201,6 +232,7 @@ __device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int3
                 }
             }
         }
+    }
     }
 }
 
@@ -273,8 +305,13 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
             n = __builtin_amdgcn_readfirstlane(n);
             chunk = __builtin_amdgcn_readfirstlane(chunk);
         }
-        const int c0 = (chunk * G + gl) * VEC;
-        if (c0 >= K) continue;
+        int c0 = (chunk * G + gl) * VEC;
+        const bool in_row = c0 < K;
+        if constexpr (WAVE_ROW) {
+            if (!in_row) c0 = 0;   // lanes past the row end stay in the wave (its lanes hand the edge ids round): they redo column 0, store nothing
+        } else if (!in_row) {
+            continue;
+        }
         int32_t beg = rowptr[n], end = rowptr[n + 1];
         if constexpr (WAVE_ROW) {
             beg = __builtin_amdgcn_readfirstlane(beg);
@@ -290,7 +327,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
         float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
         reset<VEC>(sum, sq, mn, mx);
         accumulate<T, F, MULTI, HAS_W, VEC, WAVE_ROW>(a, n, c0, beg, end, sum, sq, mn, mx);
-        finish_row<T, VEC>(a, n, c0, end - beg, sum, sq, mn, mx);
+        if (in_row) finish_row<T, VEC>(a, n, c0, end - beg, sum, sq, mn, mx);
     }
 }
 
@@ -331,8 +368,13 @@ __global__ __launch_bounds__(256) void hub_partial_kernel(const Args a) {
             if (a.piece_base[mid] <= piece) lo = mid; else hi = mid;
         }
         const int n = a.hub_rows[lo];
-        const int c0 = (chunk * G + gl) * VEC;
-        if (c0 >= K) continue;
+        int c0 = (chunk * G + gl) * VEC;
+        const bool in_row = c0 < K;
+        if constexpr (WAVE_ROW) {
+            if (!in_row) c0 = 0;
+        } else if (!in_row) {
+            continue;
+        }
         int32_t jb = a.rowptr[n] + (piece - a.piece_base[lo]) * PIECE;
         int32_t je = min(jb + PIECE, a.rowptr[n + 1]);
         if constexpr (WAVE_ROW) {
@@ -342,6 +384,7 @@ __global__ __launch_bounds__(256) void hub_partial_kernel(const Args a) {
         float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
         reset<VEC>(sum, sq, mn, mx);
         accumulate<T, F, MULTI, HAS_W, VEC, WAVE_ROW>(a, n, c0, jb, je, sum, sq, mn, mx);
+        if (!in_row) continue;
         float* pp = a.partial + (int64_t)piece * ACCS * K + c0;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -461,6 +504,8 @@ extern "C" size_t gnnops_edge_reduce_hub_workspace_bytes(int64_t E, int64_t K) {
     // below 32768 edges a hub costs one wave at most ~1.5 ms, while the three (empty) hub launches would cost every
     // launch-bound layer call on a batch of small graphs ~12 us
     if (E <= 4 * T_HUB || K <= 0) return 0;
+    const char* sw = getenv("GNNOPS_EDGE_HUBS");   // A/B (tools/time_edge_hubs.py): 0 = leave every destination to one lane group
+    if (sw && sw[0] == '0') return 0;
     return hub_layout(E, K).total;
 }
 
