@@ -109,8 +109,10 @@ class _Packed:
     def get(self, params, blocks, stack=False):
         """params: the Parameters the blocks are cut from; blocks: [(weight or a column slice of it [out, in], bias or None)]."""
         # Module.to() / .half() swap a parameter's data without touching its version counter: the pointer and dtype are in the key
-        key = tuple((id(t), t._version, t.data_ptr(), t.dtype) for t in params if t is not None)
-        if key != self.key:
+        # tensors created under torch.inference_mode() have no version counter: nothing derived from them is cached
+        cacheable = all(ops._version_of(t) is not None for t in params if t is not None)
+        key = tuple((id(t), t._version, t.data_ptr(), t.dtype) for t in params if t is not None) if cacheable else None
+        if key is None or key != self.key:
             with torch.no_grad():
                 if stack:
                     self.weight = torch.cat([wt.t() for wt, _ in blocks], dim=0).contiguous()
@@ -164,13 +166,24 @@ class GINConv(_Layer):
         else:
             self.register_buffer("eps", torch.tensor([float(eps)]))
         self._packed = _Packed()
+        self._eps_key, self._eps_host = None, float(eps)
         self._freeze()
+
+    def _eps_value(self):
+        """eps as a host number, read back from the device only when the tensor changed (a read-back per forward would
+        synchronise every call and cannot be captured into a graph)."""
+        t = self.eps
+        key = (ops._version_of(t), t.data_ptr())
+        if key[0] is None or key != self._eps_key:
+            self._eps_host = float(t)
+            self._eps_key = key
+        return self._eps_host
 
     def forward(self, x, edge_index, size=None):
         x_src, x_dst = _pair(x)
         self._forward_only(x_src, x_dst)
         n_dst = x_dst.size(0) if size is None else size[1]
-        eps = float(self.eps)
+        eps = self._eps_value()
         root = x_dst if eps == 0.0 else x_dst * (1.0 + eps)
         h = edge_reduce("copy", x_src.contiguous(), edge_index, n_dst, add=root.contiguous())
         return _linear(h, self.nn, self._packed) if isinstance(self.nn, torch.nn.Linear) else self.nn(h)

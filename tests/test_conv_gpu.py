@@ -365,6 +365,24 @@ def test_layers_are_forward_only_and_work_outside_no_grad(conv):
         layer(x, ei)
 
 
+def test_layers_under_inference_mode(conv, ora):
+    """torch.inference_mode() is the normal GNN serving setting: tensors made inside it have no version counter, so neither the
+    plan of edge_index nor the packed weights may be cached on them — and the result must still be right, call after call."""
+    g = torch.Generator().manual_seed(12)
+    ei = _graph(10, 60, 400)
+    x = _rand(g, 60, 8)
+    with torch.inference_mode():
+        layer = conv.CGConv(8, 0).cuda()                 # parameters are inference tensors too
+        xd, ed = x.cuda(), ei.cuda()
+        outs = [layer(xd, ed) for _ in range(2)]
+        layer.lin_f.weight.mul_(0.5)
+        outs.append(layer(xd, ed))
+    P = _np_params(layer)
+    want = ora.cg_conv(_f64(x), ei.numpy(), P["lin_f.weight"], P["lin_f.bias"], P["lin_s.weight"], P["lin_s.bias"])
+    _close(outs[2], want, torch.float32, "after an in-place update under inference_mode")
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+
+
 def test_layer_weights_follow_parameter_updates(conv, ora):
     """The packed weight operand is cached: an in-place update, a load_state_dict and a dtype change must all be seen."""
     torch.manual_seed(9)

@@ -48,3 +48,41 @@ def test_scatter_index_select_addmm_in_a_graph(gnnops):
                 assert torch.equal(got, exp), trial
     finally:
         gnnops.set_plan_cache(True)
+
+
+def test_message_passing_layer_in_a_graph(gnnops):
+    """A whole layer (gnnops.conv: dense product + plan + fused edge pass) is launch-bound on a batch of small graphs
+    (app_bm/benchmark_convs.py). With the plan cache OFF everything the layer does is device work on the current stream — the
+    one-launch plan included — so the call is capturable: new features AND a new edge list in the captured buffers are seen
+    by the replay, bit for bit the eager result."""
+    from gnnops import conv
+
+    torch.manual_seed(0)
+    n, e = 500, 2400
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(n, 11, generator=gen, device="cuda").half()
+    ei = torch.randint(0, n, (2, e), generator=gen, device="cuda")
+    layers = [conv.CGConv(11, 0).half().cuda(), conv.GINConv(torch.nn.Linear(11, 64)).half().cuda(), conv.SAGEConv(11, 64).half().cuda()]
+    gnnops.set_plan_cache(False)
+    try:
+        def step():
+            with torch.no_grad():
+                return [layer(x, ei) for layer in layers]
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()                                                      # warm-up: packed weights, one-time kernel attributes
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = step()
+        for trial in range(2):
+            x.copy_(torch.rand(n, 11, generator=gen, device="cuda").half())
+            ei.copy_(torch.randint(0, n, (2, e), generator=gen, device="cuda"))
+            graph.replay()
+            torch.cuda.synchronize()
+            for got, exp in zip(outs, step()):
+                assert torch.equal(got, exp), trial
+    finally:
+        gnnops.set_plan_cache(True)
