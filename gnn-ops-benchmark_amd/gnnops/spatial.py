@@ -166,6 +166,8 @@ def fps(x, batch=None, ratio=0.5, random_start=True):
     """torch_cluster.fps(x, batch=None, ratio=0.5, random_start=True) -> indices of the sampled points, batch after batch:
     ceil(ratio * n_b) per batch, each the point farthest from those already chosen (ties: the smaller index)."""
     x = _points(x, "fps")
+    if not 0.0 < float(ratio) <= 1.0:
+        raise ValueError("fps: ratio must be in (0, 1]")
     dt = _dtype_code(x, "fps")
     N, D = x.shape
     dev = x.device
