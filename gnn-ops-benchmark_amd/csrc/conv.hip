@@ -104,16 +104,23 @@ __device__ inline void store_vec(T* p, const float* f) {
 // one v_exp + one v_rcp for the sigmoid; one v_exp + one v_log for the softplus.
 __device__ inline float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
 // softplus(x) = max(x, 0) + log1p(exp(-|x|)). torch's form (beta 1, threshold 20: x itself above 20) is the same number in
-// fp32: above 20 the log1p term is < 2.1e-9, below half an ulp of x. log1p by its series where 1 + t would round t away;
-// elsewhere 1 + t is in [1, 2], so the bare v_log_f32 needs none of logf's range handling.
+// fp32: above 20 the log1p term is < 2.1e-9, below half an ulp of x. fp32 storage: log1p by its series where 1 + t would
+// round t away; elsewhere 1 + t is in [1, 2], so the bare v_log_f32 needs none of logf's range handling.
+template <bool PRECISE>
 __device__ inline float softplus_f(float x) {
     const float t = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504f);
-    const float series = t * (1.f - t * (0.5f - t * (1.f / 3.f)));
     const float lg = __builtin_amdgcn_logf(1.f + t) * 0.693147181f;
-    return fmaxf(x, 0.f) + (t < 1e-3f ? series : lg);
+    if constexpr (PRECISE) {
+        const float series = t * (1.f - t * (0.5f - t * (1.f / 3.f)));
+        return fmaxf(x, 0.f) + (t < 1e-3f ? series : lg);
+    } else {
+        // 16-bit storage: 1 + t rounds t to 2^-24, an absolute error of 6e-8 in a message that is rounded to 2^-11 (fp16) or
+        // 2^-8 (bf16) of the row's sum afterwards — the series is six instructions per element the result cannot show
+        return fmaxf(x, 0.f) + lg;
+    }
 }
 
-template <int F, bool HAS_W, int VEC>
+template <int F, bool HAS_W, int VEC, bool PRECISE>
 __device__ inline void message(const float (*pv)[VEC], const float (*qv)[VEC], const float (*wv)[VEC], float* m) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -126,7 +133,7 @@ __device__ inline void message(const float (*pv)[VEC], const float (*qv)[VEC], c
         } else if constexpr (F == F_CGCONV) {
             float f = pv[0][v] + qv[0][v], s = pv[1][v] + qv[1][v];
             if constexpr (HAS_W) { f = f + wv[0][v]; s = s + wv[1][v]; }
-            m[v] = sigmoid_f(f) * softplus_f(s);
+            m[v] = sigmoid_f(f) * softplus_f<PRECISE>(s);
         } else {   // F_FILM: beta = part 0, gamma = part 1
             m[v] = fmaxf(pv[1][v] * qv[0][v] + pv[0][v], 0.f);
         }
@@ -141,7 +148,8 @@ __device__ inline void message(const float (*pv)[VEC], const float (*qv)[VEC], c
 // the 16-B lanes (fewest memory instructions; they are bandwidth-bound).
 // the edges [jb, je) of destination n folded into the running accumulators (columns c0 .. c0 + VEC of every part)
 template <typename T, int F, bool MULTI, bool HAS_W, int VEC, bool WAVE_ROW>
-__device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int32_t je, float* sum, float* sq, float* mn, float* mx) {
+__device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int32_t je, float* sum, float* sq, float* mn, float* mx,
+                                  bool have_first = false, int cl_first = 0, int el_first = 0) {
     constexpr int U = Parts<F>::Q == 2 ? 4 : 8;
     constexpr int NQ = Parts<F>::Q, NP = Parts<F>::P > 0 ? Parts<F>::P : 1, NW = Parts<F>::W > 0 ? Parts<F>::W : 1;
     const T* __restrict__ q = (const T*)a.q;
@@ -150,6 +158,10 @@ __device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int3
     const int32_t* __restrict__ perm = a.perm;
     const int64_t* __restrict__ col = a.col;
     const int K = (int)a.K, ldq = (int)a.ldq, ldw = (int)a.ldw;   // < 2^31 (host-checked): row offsets are one 32 x 32 -> 64 multiply
+    if constexpr (WAVE_ROW) {   // the edge loop, its bounds checks and the row base addresses are scalar work here
+        jb = __builtin_amdgcn_readfirstlane(jb);
+        je = __builtin_amdgcn_readfirstlane(je);
+    }
     float pv[NP][VEC];
     if constexpr (Parts<F>::P > 0) {
 #pragma unroll
@@ -162,7 +174,10 @@ __device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int3
     int cl = 0, el = 0;
     const int32_t jrun_end = WAVE_ROW ? min(jrun + 64, je) : je;
     if constexpr (WAVE_ROW) {
-        if (jrun + lane < je) {
+        if (have_first && jrun == jb) {   // the caller fetched this run's ids an iteration ago (edge_reduce_kernel's pipeline)
+            cl = cl_first;
+            el = el_first;
+        } else if (jrun + lane < je) {
             cl = (int)col[jrun + lane];
             if constexpr (HAS_W) el = perm ? perm[jrun + lane] : jrun + lane;
         }
@@ -190,23 +205,37 @@ __device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int3
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {       // ... their row addresses: every wait for an id happens HERE, because ...
-            qrow[u] = (int64_t)c[u] * ldq + c0;      // element offsets, not pointers: a pointer through asm loses its address space
-            if constexpr (HAS_W) wrow[u] = (int64_t)e[u] * ldw + c0;
+            qrow[u] = (int64_t)c[u] * ldq;      // element offsets, not pointers: a pointer through asm loses its address space
+            if constexpr (HAS_W) wrow[u] = (int64_t)e[u] * ldw;
             // ... the empty volatile statements pin the address arithmetic to this spot. Left alone, the compiler sinks each
             // address into the guarded block of its row load, and the wait for id u lands between two row loads — where it
             // also waits for every row already in flight (vmcnt counts in order): a vmcnt(0) before every row load in one
             // build of this loop (gather-sum 3.5 -> 4.0 ms, cgconv 8.9 -> 10.7 ms at N = 10M, E = 50M).
-            asm volatile("" : "+v"(qrow[u]));
-            if constexpr (HAS_W) asm volatile("" : "+v"(wrow[u]));
+            if constexpr (WAVE_ROW) {           // ids are scalars: the row base stays in SGPRs, the lane's column is the load's VGPR offset
+                asm volatile("" : "+s"(qrow[u]));
+                if constexpr (HAS_W) asm volatile("" : "+s"(wrow[u]));
+            } else {
+                qrow[u] += c0;
+                if constexpr (HAS_W) wrow[u] += c0;
+                asm volatile("" : "+v"(qrow[u]));
+                if constexpr (HAS_W) asm volatile("" : "+v"(wrow[u]));
+            }
         }
+        const uint32_t lane_off = WAVE_ROW ? (uint32_t)c0 * (uint32_t)sizeof(T) : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {       // ... then all its row loads in flight together (raw words: no conversion here)
             if (j + u < jrun_end) {
 #pragma unroll
-                for (int r = 0; r < NQ; ++r) qr[u][r] = load_raw<T, VEC>(q + qrow[u] + r * K, a.nt != 0);
+                for (int r = 0; r < NQ; ++r) {
+                    const T* row = q + qrow[u] + r * K;
+                    qr[u][r] = load_raw<T, VEC>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + lane_off), a.nt != 0);
+                }
                 if constexpr (HAS_W) {
 #pragma unroll
-                    for (int r = 0; r < NW; ++r) wr[u][r] = load_raw<T, VEC>(w + wrow[u] + r * K, true);
+                    for (int r = 0; r < NW; ++r) {
+                        const T* row = w + wrow[u] + r * K;
+                        wr[u][r] = load_raw<T, VEC>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + lane_off), true);
+                    }
                 }
             }
         }
@@ -220,7 +249,7 @@ __device__ inline void accumulate(const Args& a, int n, int c0, int32_t jb, int3
 #pragma unroll
                     for (int r = 0; r < NW; ++r) unpack_vec<T, VEC>(wr[u][r], wv[r]);
                 }
-                message<F, HAS_W, VEC>(pv, qv, wv, m);
+                message<F, HAS_W, VEC, sizeof(T) == 4>(pv, qv, wv, m);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     sum[v] += m[v];
@@ -243,8 +272,24 @@ __device__ inline void finish_row(const Args& a, int n, int c0, int32_t cnt, con
     const T* __restrict__ add = (const T*)a.add;
     const int K = (int)a.K;
     const float degc = (float)(cnt < 1 ? 1 : cnt);
-    const float logd = __logf(degc + 1.f);
     T* orow = (T*)a.out + (int64_t)n * a.ldo + c0;
+    // The common layers (GIN / SAGE / CGConv / FiLM) want ONE block, sum or mean, no scaler: a handful of instructions. The
+    // general form below costs ~500 per row (a logarithm, eight IEEE divisions and a square root that the compiler hoists out
+    // of the aggregator switch) — twice the arithmetic of the five cgconv messages of an average row when it ran for every row.
+    if (a.n_scal == 1 && a.scal[0] == S_IDENTITY && a.n_aggr == 1 && a.aggr[0] <= A_MEAN) {
+        float o[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = a.aggr[0] == A_MEAN ? sum[v] / degc : sum[v];
+        if (add) {
+            float t[VEC];
+            load_vec<T, VEC>(add + (int64_t)n * a.ldadd + c0, t);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] += t[v];
+        }
+        store_vec<T, VEC>(orow, o);
+        return;
+    }
+    const float logd = __logf(degc + 1.f);
     for (int s = 0; s < a.n_scal; ++s) {
         float scale = 1.f;
         switch (a.scal[s]) {
@@ -298,36 +343,86 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const Args a) {
     const int64_t items = (int64_t)a.kchunks * a.N;
     const int K = (int)a.K;
 
-    for (int64_t item = gtid >> a.gshift; item < items; item += ngroups) {
-        int n, chunk;
-        if (a.kchunks == 1) { n = (int)item; chunk = 0; } else { n = (int)(item % a.N); chunk = (int)(item / a.N); }
-        if constexpr (WAVE_ROW) {   // the whole wave is on this row: row bounds, edge ids and the loop itself are scalar
+    if constexpr (WAVE_ROW) {
+        // The whole wave is on one row: bounds, edge ids and the edge loop are scalar. A row is a chain of three dependent
+        // memory latencies — rowptr -> edge ids -> gathered rows — and a wave has ~10 elements per lane to compute per row,
+        // so the chain, not the arithmetic, set the pace (~6 ms of the 9 ms of cgconv D = 128 fp16 at N = 10M). The loop is
+        // software-pipelined over the wave's rows: while row k is reduced, the ids of row k+1 and the bounds of row k+2 are
+        // already in flight.
+        const int64_t* __restrict__ col = a.col;
+        const int32_t* __restrict__ perm = a.perm;
+        auto decode = [&](int64_t it, int& n, int& chunk) {
+            if (a.kchunks == 1) { n = (int)it; chunk = 0; } else { n = (int)(it % a.N); chunk = (int)(it / a.N); }
             n = __builtin_amdgcn_readfirstlane(n);
             chunk = __builtin_amdgcn_readfirstlane(chunk);
+        };
+        int64_t it0 = gtid >> 6;
+        if (it0 >= items) return;
+        int n0, ch0, n1 = 0, ch1 = 0;
+        decode(it0, n0, ch0);
+        int32_t b0 = rowptr[n0], e0 = rowptr[n0 + 1], b1 = 0, e1 = 0;
+        int64_t it1 = it0 + ngroups;
+        bool has1 = it1 < items;
+        if (has1) { decode(it1, n1, ch1); b1 = rowptr[n1]; e1 = rowptr[n1 + 1]; }
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        e0 = __builtin_amdgcn_readfirstlane(e0);
+        int cl0 = 0, el0 = 0;
+        if (b0 + gl < e0) {
+            cl0 = (int)col[b0 + gl];
+            if constexpr (HAS_W) el0 = perm ? perm[b0 + gl] : b0 + gl;
         }
-        int c0 = (chunk * G + gl) * VEC;
-        const bool in_row = c0 < K;
-        if constexpr (WAVE_ROW) {
-            if (!in_row) c0 = 0;   // lanes past the row end stay in the wave (its lanes hand the edge ids round): they redo column 0, store nothing
-        } else if (!in_row) {
-            continue;
-        }
-        int32_t beg = rowptr[n], end = rowptr[n + 1];
-        if constexpr (WAVE_ROW) {
-            beg = __builtin_amdgcn_readfirstlane(beg);
-            end = __builtin_amdgcn_readfirstlane(end);
-        }
-        if (a.hub_count && end - beg > T_HUB) {   // a hub: set aside for the piecewise pass, neither reduced nor stored here
-            if (gl == 0 && chunk == 0) {
-                const unsigned int slot = atomicAdd(a.hub_count, 1u);
-                if ((int)slot < a.max_hubs) a.hub_rows[slot] = n;
+        while (true) {
+            const int64_t it2 = it1 + ngroups;
+            const bool has2 = has1 && it2 < items;
+            int n2 = 0, ch2 = 0, cl1 = 0, el1 = 0;
+            int32_t b2 = 0, e2 = 0;
+            if (has2) { decode(it2, n2, ch2); b2 = rowptr[n2]; e2 = rowptr[n2 + 1]; }   // bounds of row k+2: used an iteration from now
+            if (has1) {                                                                    // ids of row k+1: its bounds were fetched an iteration ago
+                b1 = __builtin_amdgcn_readfirstlane(b1);
+                e1 = __builtin_amdgcn_readfirstlane(e1);
+                if (b1 + gl < e1) {
+                    cl1 = (int)col[b1 + gl];
+                    if constexpr (HAS_W) el1 = perm ? perm[b1 + gl] : b1 + gl;
+                }
             }
-            continue;
+            // row k
+            int c0 = (ch0 * G + gl) * VEC;
+            const bool in_row = c0 < K;
+            if (!in_row) c0 = 0;   // lanes past the row end stay in the wave (its lanes hand the edge ids round): they redo column 0, store nothing
+            if (a.hub_count && e0 - b0 > T_HUB) {   // a hub: set aside for the piecewise pass, neither reduced nor stored here
+                if (gl == 0 && ch0 == 0) {
+                    const unsigned int slot = atomicAdd(a.hub_count, 1u);
+                    if ((int)slot < a.max_hubs) a.hub_rows[slot] = n0;
+                }
+            } else {
+                float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
+                reset<VEC>(sum, sq, mn, mx);
+                accumulate<T, F, MULTI, HAS_W, VEC, true>(a, n0, c0, b0, e0, sum, sq, mn, mx, true, cl0, el0);
+                if (in_row) finish_row<T, VEC>(a, n0, c0, e0 - b0, sum, sq, mn, mx);
+            }
+            if (!has1) break;
+            n0 = n1; ch0 = ch1; b0 = b1; e0 = e1; cl0 = cl1; el0 = el1;
+            it1 = it2; has1 = has2; n1 = n2; ch1 = ch2; b1 = b2; e1 = e2;
         }
-        float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
-        reset<VEC>(sum, sq, mn, mx);
-        accumulate<T, F, MULTI, HAS_W, VEC, WAVE_ROW>(a, n, c0, beg, end, sum, sq, mn, mx);
-        if (in_row) finish_row<T, VEC>(a, n, c0, end - beg, sum, sq, mn, mx);
+    } else {
+        for (int64_t item = gtid >> a.gshift; item < items; item += ngroups) {
+            int n, chunk;
+            if (a.kchunks == 1) { n = (int)item; chunk = 0; } else { n = (int)(item % a.N); chunk = (int)(item / a.N); }
+            const int c0 = (chunk * G + gl) * VEC;
+            if (c0 >= K) continue;
+            const int32_t beg = rowptr[n], end = rowptr[n + 1];
+            if (a.hub_count && end - beg > T_HUB) {   // a hub: set aside for the piecewise pass, neither reduced nor stored here
+                if (gl == 0 && chunk == 0) {
+                    const unsigned int slot = atomicAdd(a.hub_count, 1u);
+                    if ((int)slot < a.max_hubs) a.hub_rows[slot] = n;
+                }
+                continue;
+            }
+            float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
+            reset<VEC>(sum, sq, mn, mx);
+            accumulate<T, F, MULTI, HAS_W, VEC, false>(a, n, c0, beg, end, sum, sq, mn, mx);
+            finish_row<T, VEC>(a, n, c0, end - beg, sum, sq, mn, mx);
+        }
     }
 }
 
