@@ -289,14 +289,25 @@ __device__ inline void finish_row(const Args& a, int n, int c0, int32_t cnt, con
         store_vec<T, VEC>(orow, o);
         return;
     }
-    const float logd = __logf(degc + 1.f);
+    // General form (PNAConv: several aggregators x degree scalers). Everything that depends on the row only is computed once:
+    // ONE division (1 / deg) and the bare v_log / v_rcp / v_sqrt instructions — as first written (sum / deg per element and
+    // aggregator, logf, sqrtf) this epilogue was ~500 vector instructions per row and bounded the whole PNA pass.
+    const float inv_deg = 1.f / degc;
+    const float logd = __builtin_amdgcn_logf(degc + 1.f) * 0.693147181f;
+    float mean[VEC], stdv[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        mean[v] = sum[v] * inv_deg;
+        // sqrt(relu(mean(m^2) - mean(m)^2) + 1e-5), PNAConv.aggregate
+        stdv[v] = __builtin_amdgcn_sqrtf(fmaxf(sq[v] * inv_deg - mean[v] * mean[v], 0.f) + 1e-5f);
+    }
     for (int s = 0; s < a.n_scal; ++s) {
         float scale = 1.f;
         switch (a.scal[s]) {
-            case S_AMPLIFICATION: scale = logd / a.avg_log; break;
-            case S_ATTENUATION: scale = a.avg_log / logd; break;
-            case S_LINEAR: scale = degc / a.avg_lin; break;
-            case S_INVERSE_LINEAR: scale = a.avg_lin / degc; break;
+            case S_AMPLIFICATION: scale = logd * __builtin_amdgcn_rcpf(a.avg_log); break;
+            case S_ATTENUATION: scale = a.avg_log * __builtin_amdgcn_rcpf(logd); break;
+            case S_LINEAR: scale = degc * __builtin_amdgcn_rcpf(a.avg_lin); break;
+            case S_INVERSE_LINEAR: scale = a.avg_lin * inv_deg; break;
             default: break;
         }
         for (int g = 0; g < a.n_aggr; ++g) {
@@ -306,13 +317,10 @@ __device__ inline void finish_row(const Args& a, int n, int c0, int32_t cnt, con
                 float r;
                 switch (a.aggr[g]) {
                     case A_SUM: r = sum[v]; break;
-                    case A_MEAN: r = sum[v] / degc; break;
+                    case A_MEAN: r = mean[v]; break;
                     case A_MIN: r = cnt > 0 ? mn[v] : 0.f; break;
                     case A_MAX: r = cnt > 0 ? mx[v] : 0.f; break;
-                    default: {   // A_STD: sqrt(relu(mean(m^2) - mean(m)^2) + 1e-5), PNAConv.aggregate
-                        const float mean = sum[v] / degc;
-                        r = __fsqrt_rn(fmaxf(sq[v] / degc - mean * mean, 0.f) + 1e-5f);
-                    }
+                    default: r = stdv[v]; break;
                 }
                 o[v] = r * scale;
             }
