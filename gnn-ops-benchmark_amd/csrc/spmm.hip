@@ -48,15 +48,19 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
         for (int32_t j = beg; j < end; j += U) {
             int64_t c[U];
-            float w[U];
-            u32x4 rows[U];
+            T wraw[U];      // the value as STORED: converting it where it is loaded would put a wait for the load right there, and
+            u32x4 rows[U];  // the U (column id, value) pairs of a step would be fetched one memory latency after the other
+            // three phases, each with all its loads in flight together: positions (plan order only), then (column id, value)
+            // pairs, then the gathered rows. Interleaved per nonzero, every position -> column -> row chain waited on its own.
+            int32_t e[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = (j + u < end) ? (perm ? perm[j + u] : j + u) : -1;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 c[u] = -1;
-                if (j + u < end) {
-                    const int32_t e = perm ? perm[j + u] : (j + u);
-                    c[u] = col[e];
-                    w[u] = value ? Elem<T>::load(value + e) : 1.f;
+                if (e[u] >= 0) {
+                    c[u] = col[e[u]];
+                    if (value) wraw[u] = value[e[u]];
                 }
             }
 #pragma unroll
@@ -67,8 +71,9 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
                 if (c[u] >= 0) {
                     float f[VEC];
                     Elem<T>::unpack(rows[u], f);
+                    const float w = value ? Elem<T>::load(&wraw[u]) : 1.f;
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(w[u], f[v]));
+                    for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(w, f[v]));
                 }
             }
         }
