@@ -335,28 +335,63 @@ __global__ __launch_bounds__(256) void select_sum_rows_kernel(const T* __restric
     const int gl = (int)(gtid & (G - 1));
     const int64_t items = B * (int64_t)chunks * E;
     float acc = 0.f;
+    // One matrix, one column chunk (BASELINE config 4 and every row of at most 1 KiB): item = position in `index`, no
+    // divisions. The RIF index entries of a step are loaded first, then the RIF row addresses are formed (and pinned: the
+    // compiler otherwise sinks each into its guarded load and waits for index u between two row loads, which also waits for
+    // the rows in flight), then the RIF rows are loaded together. Offsets from the typed base pointer, not nullable
+    // pointers — those lose their address space and become flat loads that wait on both counters.
+    const bool simple = B == 1 && chunks == 1;
+    const bool whole = simple && (int64_t)G * VEC == K;   // every lane of a group has a column: no per-lane guard at all
     for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * RIF) {
-        const T* p[RIF];
+        if (whole && item0 + (int64_t)(RIF - 1) * ngroups < items) {
+            // full step, straight-line: RIF index entries, then RIF rows, all in flight, nothing guarded (guarded loads get a
+            // vmcnt(0) each from the compiler's wait insertion — the RIF rows of a step then arrive one after the other)
+            int64_t idx[RIF];
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) idx[u] = index[item0 + (int64_t)u * ngroups];
+            u32x4 v[RIF];
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) v[u] = load16<true>(in + idx[u] * K + (int64_t)gl * VEC);
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                float f[VEC];
+                Elem<T>::unpack(v[u], f);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc += f[q];
+            }
+            continue;
+        }
+        int64_t off[RIF];
+        bool ok[RIF];
 #pragma unroll
         for (int u = 0; u < RIF; ++u) {
             const int64_t item = item0 + (int64_t)u * ngroups;
-            p[u] = nullptr;
+            ok[u] = false;
+            off[u] = 0;
             if (item < items) {
-                const int64_t e = item % E;
-                const int64_t bc = item / E;
-                const int c = (int)(bc % chunks);
-                const int64_t b = bc / chunks;
-                const int64_t col = ((int64_t)c * G + gl) * VEC;
-                if (col < K) p[u] = in + (b * N + index[e]) * K + col;
+                int64_t e = item, b = 0, col = (int64_t)gl * VEC;
+                if (!simple) {
+                    e = item % E;
+                    const int64_t bc = item / E;
+                    const int c = (int)(bc % chunks);
+                    b = bc / chunks;
+                    col = ((int64_t)c * G + gl) * VEC;
+                }
+                if (col < K) {
+                    ok[u] = true;
+                    off[u] = (b * N + index[e]) * K + col;
+                }
             }
         }
+#pragma unroll
+        for (int u = 0; u < RIF; ++u) asm volatile("" : "+v"(off[u]));
         u32x4 v[RIF];
 #pragma unroll
         for (int u = 0; u < RIF; ++u)
-            if (p[u]) v[u] = load16<true>(p[u]);
+            if (ok[u]) v[u] = load16<true>(in + off[u]);
 #pragma unroll
         for (int u = 0; u < RIF; ++u) {
-            if (p[u]) {
+            if (ok[u]) {
                 float f[VEC];
                 Elem<T>::unpack(v[u], f);
 #pragma unroll
