@@ -23,7 +23,22 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const char* __restrict
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
     const int gl = (int)(gtid & (G - 1));
     const int64_t items = B * (int64_t)chunks * E;
+    // one matrix, one chunk, every lane of a group on a piece of the row: item = position in `index`
+    const bool whole = B == 1 && chunks == 1 && (int64_t)G * 16 == rowbytes;
     for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * RIF) {
+        if (whole && item0 + (int64_t)(RIF - 1) * ngroups < items) {
+            // full step, straight-line: RIF index entries, RIF row pieces, RIF stores — every load of a phase in flight
+            // (guarded loads each get a vmcnt(0) from the compiler's wait insertion, and nullable pointers become flat loads)
+            int64_t n[RIF];
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) n[u] = index[item0 + (int64_t)u * ngroups];
+            u32x4 v[RIF];
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) v[u] = load16<NT_LD>(in + n[u] * rowbytes + (int64_t)gl * 16);
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) store16<NT_ST>(out + (item0 + (int64_t)u * ngroups) * rowbytes + (int64_t)gl * 16, v[u]);
+            continue;
+        }
         const char* sp[RIF];
         char* dp[RIF];
 #pragma unroll
