@@ -53,10 +53,18 @@ __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restr
         const float* src = in + row * E_total + off;
         uint32_t key[ROUNDS];
         uint32_t px[ROUNDS];  // source position in the high half; the low half is scratch for the ranking
+        // the row's elements: ALL loads first (clamped index, nothing guarded), the key transform afterwards — transformed
+        // where it is loaded, every element waited for its own load: ROUNDS memory latencies one after the other per row
+        float raw[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int i = wave_base + r * 64 + lane;
-            uint32_t k = (i < E) ? f32_key(src[i]) : 0u;
+            raw[r] = src[i < E ? i : E - 1];
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int i = wave_base + r * 64 + lane;
+            uint32_t k = (i < E) ? f32_key(raw[r]) : 0u;
             key[r] = descending ? ~k : k;
             px[r] = (uint32_t)i << 16;
         }

@@ -137,10 +137,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in
     in += (int64_t)blockIdx.z * R * C;   // batch of independent [R, C] matrices
     out += (int64_t)blockIdx.z * R * C;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    if (r0 + 64 <= R && c0 + 64 <= C) {   // interior tile: the sixteen loads are issued together, then parked in LDS
+        U v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int64_t r = r0 + ty + 4 * j, c = c0 + tx;
-        if (r < R && c < C) tile[ty + 4 * j][tx] = in[r * C + c];
+        for (int j = 0; j < 16; ++j) v[j] = in[(r0 + ty + 4 * j) * C + c0 + tx];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tile[ty + 4 * j][tx] = v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t r = r0 + ty + 4 * j, c = c0 + tx;
+            if (r < R && c < C) tile[ty + 4 * j][tx] = in[r * C + c];
+        }
     }
     __syncthreads();
 #pragma unroll
