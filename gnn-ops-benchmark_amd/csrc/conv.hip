@@ -17,9 +17,12 @@
 //   AGGR = sum, mean, min, max, std — any ordered subset in the same pass (PNAConv: mean, min, max, std), each optionally
 //   multiplied by PNA's degree scalers, written side by side into a row of pitch `ldo` (so the layer's torch.cat never runs).
 //
-// One lane group per (destination row, 16-B column chunk) exactly as segment.hip / spmm.hip: each gathered row is read once,
-// each output row stored once, messages live in registers, fp32 arithmetic, ONE rounding on store. Algorithmic bytes per
-// launch: E * (q row + 8 B column id (+ w row)) + N * (p row + out row) + 4 (N + 1).
+// One lane group per (destination row, column chunk) as in segment.hip / spmm.hip — 16-B lanes for the bandwidth-bound
+// messages, ONE ROW PER WAVE (4-byte lanes, scalar edge ids, rows software-pipelined) for the arithmetic-heavy ones (see
+// edge_reduce_kernel): each gathered row is read once, each output row stored once, messages live in registers, fp32
+// arithmetic, ONE rounding on store. Destinations with more than 8192 edges are reduced piecewise (hub passes below).
+// Algorithmic bytes per launch: E * (q row + 8 B column id (+ w row)) + N * (p row + out row) + 4 (N + 1); measured traffic
+// and the optimisation ladder: DESIGN.md §4 "Message-passing layers", profiles/round2_f_*.
 #include "common.h"
 #include <stdlib.h>
 
