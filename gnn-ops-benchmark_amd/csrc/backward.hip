@@ -111,8 +111,10 @@ __global__ __launch_bounds__(256) void owner_counts_kernel(const int64_t* __rest
         int owner = -1;
         if (e < E) {
             const int64_t d = index[e];
-            owner = 0;
-            for (int g = 1; g < G; ++g) owner += (d >= (int64_t)g * per) ? 1 : 0;
+            if (d >= 0 && d < (int64_t)G * per) {   // an id outside [0, G * per) is counted for NO owner: the counts then do not
+                owner = 0;                           // add up to E and the caller (dist.py) raises instead of misrouting the edge
+                for (int g = 1; g < G; ++g) owner += (d >= (int64_t)g * per) ? 1 : 0;
+            }
         }
         for (int g = 0; g < G; ++g) {
             const unsigned long long m = __ballot(owner == g);

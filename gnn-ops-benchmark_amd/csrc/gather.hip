@@ -19,31 +19,35 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const char* __restrict
                                                           char* __restrict__ out, int64_t B, int64_t N, int64_t E,
                                                           int64_t rowbytes, int gshift, int chunks) {
     const int G = 1 << gshift;
-    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
-    const int gl = (int)(gtid & (G - 1));
+    const int gl = threadIdx.x & (G - 1);
+    const int gi = threadIdx.x >> gshift, groups = 256 >> gshift;
     const int64_t items = B * (int64_t)chunks * E;
     // one matrix, one chunk, every lane of a group on a piece of the row: item = position in `index`
     const bool whole = B == 1 && chunks == 1 && (int64_t)G * 16 == rowbytes;
-    for (int64_t item0 = gtid >> gshift; item0 < items; item0 += ngroups * RIF) {
-        if (whole && item0 + (int64_t)(RIF - 1) * ngroups < items) {
+    // A workgroup step covers groups * RIF CONSECUTIVE items: its RIF stores per lane are one contiguous run of output
+    // rows, issued back to back (tools/micro/store_sweep.hip: a 1 : 1 copy in that shape runs at 5.8-5.9 TB/s, grid-strided
+    // 16-B lanes at 5.0-5.5).
+    const int64_t step_items = (int64_t)groups * RIF;
+    for (int64_t step = blockIdx.x; step * step_items < items; step += gridDim.x) {
+        const int64_t item0 = step * step_items + gi;
+        if (whole && (step + 1) * step_items <= items) {
             // full step, straight-line: RIF index entries, RIF row pieces, RIF stores — every load of a phase in flight
             // (guarded loads each get a vmcnt(0) from the compiler's wait insertion, and nullable pointers become flat loads)
             int64_t n[RIF];
 #pragma unroll
-            for (int u = 0; u < RIF; ++u) n[u] = index[item0 + (int64_t)u * ngroups];
+            for (int u = 0; u < RIF; ++u) n[u] = index[item0 + u * groups];
             u32x4 v[RIF];
 #pragma unroll
             for (int u = 0; u < RIF; ++u) v[u] = load16<NT_LD>(in + n[u] * rowbytes + (int64_t)gl * 16);
 #pragma unroll
-            for (int u = 0; u < RIF; ++u) store16<NT_ST>(out + (item0 + (int64_t)u * ngroups) * rowbytes + (int64_t)gl * 16, v[u]);
+            for (int u = 0; u < RIF; ++u) store16<NT_ST>(out + (item0 + u * groups) * rowbytes + (int64_t)gl * 16, v[u]);
             continue;
         }
         const char* sp[RIF];
         char* dp[RIF];
 #pragma unroll
         for (int u = 0; u < RIF; ++u) {
-            const int64_t item = item0 + (int64_t)u * ngroups;
+            const int64_t item = item0 + u * groups;
             sp[u] = nullptr;
             dp[u] = nullptr;
             if (item < items) {

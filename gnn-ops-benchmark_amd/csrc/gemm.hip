@@ -1368,6 +1368,10 @@ extern "C" int gnnops_addmm_ld(const void* input, int64_t ldadd, const void* mat
     GNNOPS_REQUIRE(dtype == GNNOPS_F16 || dtype == GNNOPS_BF16 || dtype == GNNOPS_F32, GNNOPS_EUNSUPPORTED,
                    "addmm: unknown dtype code %d", dtype);
     GNNOPS_REQUIRE(ldadd == 0 || ldadd >= N, GNNOPS_EINVAL, "addmm: input row pitch must be 0 (one row for all) or >= N");
+    // the epilogues' 16-B loads of the addend test its POINTER and N only: a pitch that is neither N nor a multiple of 16 bytes
+    // would put rows 1.. on misaligned addresses
+    GNNOPS_REQUIRE(ldadd == 0 || ldadd == N || (ldadd * (dtype == GNNOPS_F32 ? 4 : 2)) % 16 == 0, GNNOPS_EINVAL,
+                   "addmm: an input row pitch other than 0 or N must be a multiple of 16 bytes (got %lld elements)", (long long)ldadd);
     if (M * N == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(out && (K == 0 || (mat1 && mat2)), GNNOPS_EINVAL, "addmm: null pointer");
     // the row-tile index travels in gridDim.y (< 65536): taller problems (a node-feature matrix of BASELINE config 2's

@@ -662,8 +662,12 @@ extern "C" int gnnops_scatter_elementwise_ix(const void* src, const void* index,
 namespace {
 // int64 -> int32 / uint16, streaming: 16-B loads (two entries), 8-B / 4-B stores; eight loads in flight per lane
 template <typename O>
-__global__ __launch_bounds__(256) void narrow_index_kernel(const int64_t* __restrict__ in, O* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(256) void narrow_index_kernel(const int64_t* __restrict__ in, O* __restrict__ out, int64_t n,
+                                                           int64_t bound) {
     typedef long long ll2_t __attribute__((ext_vector_type(2)));
+    // an id outside [0, bound) becomes the all-ones pattern (-1 / 0xFFFF, never a valid id: bound <= 65535 for two bytes), so
+    // the element kernels drop it exactly as they drop it when they read the int64 index — not a wrapped-around valid id
+    auto nar = [bound](long long v) -> O { return (v >= 0 && v < bound) ? (O)v : (O)~(O)0; };
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     const bool vec = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % (2 * sizeof(O)) == 0);
     const int64_t n2 = vec ? n / 2 : 0;
@@ -676,29 +680,30 @@ __global__ __launch_bounds__(256) void narrow_index_kernel(const int64_t* __rest
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             O* q = out + 2 * (i + u * stride);
-            q[0] = (O)v[u].x;
-            q[1] = (O)v[u].y;
+            q[0] = nar(v[u].x);
+            q[1] = nar(v[u].y);
         }
     }
     for (; i < n2; i += stride) {
         const ll2_t a = __builtin_nontemporal_load(p + i);
-        out[2 * i] = (O)a.x;
-        out[2 * i + 1] = (O)a.y;
+        out[2 * i] = nar(a.x);
+        out[2 * i + 1] = nar(a.y);
     }
-    for (int64_t j = 2 * n2 + gtid; j < n; j += stride) out[j] = (O)in[j];
+    for (int64_t j = 2 * n2 + gtid; j < n; j += stride) out[j] = nar(in[j]);
 }
 }  // namespace
 
-// out[i] = (int32 / uint16) index[i]: the narrowed copy gnnops_scatter_elementwise_ix / gnnops_gather_ix read. Values must
-// fit (the caller knows the bound: every entry lies in [0, N)).
-extern "C" int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_bytes, gnnops_stream_t s) {
-    GNNOPS_REQUIRE(n >= 0 && (out_bytes == 4 || out_bytes == 2), GNNOPS_EINVAL, "narrow_index: bad argument");
+// out[i] = (int32 / uint16) index[i] for ids in [0, bound), all ones otherwise: the narrowed copy
+// gnnops_scatter_elementwise_ix reads. bound <= 65535 for two bytes, < 2^31 for four.
+extern "C" int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_bytes, int64_t bound, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(n >= 0 && bound >= 0 && ((out_bytes == 4 && bound < ((int64_t)1 << 31)) || (out_bytes == 2 && bound <= 65535)),
+                   GNNOPS_EINVAL, "narrow_index: bad argument (out_bytes=%d bound=%lld)", out_bytes, (long long)bound);
     if (n == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(index && out, GNNOPS_EINVAL, "narrow_index: null pointer");
     const int grid = gnnops_grid_cap(gnnops_cdiv(n, 256 * 16), 256 * 8);
     if (out_bytes == 4)
-        hipLaunchKernelGGL(narrow_index_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, index, (int32_t*)out, n);
+        hipLaunchKernelGGL(narrow_index_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, index, (int32_t*)out, n, bound);
     else
-        hipLaunchKernelGGL(narrow_index_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, index, (uint16_t*)out, n);
+        hipLaunchKernelGGL(narrow_index_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, index, (uint16_t*)out, n, bound);
     return gnnops_check_launch("narrow_index");
 }

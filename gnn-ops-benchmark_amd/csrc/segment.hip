@@ -20,6 +20,7 @@ constexpr int U = 8;       // contribution rows in flight per lane group
 // Source rows and output rows are touched exactly once: nontemporal accesses keep them from evicting
 // rowptr / perm lines (measured -5 % kernel time at config 2; tools/time_seg.py).
 constexpr bool NT = true;
+constexpr int SEG_BLOCK = 256;   // consecutive items (output rows) a workgroup of seg_rows_kernel takes at a time
 
 // Row form: the row is K elements, K % VEC == 0, 16-B aligned. A group of G = 2^gshift lanes owns one
 // (b, n, chunk) item; chunk c covers elements [c*G*VEC, (c+1)*G*VEC).
@@ -32,12 +33,18 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
     constexpr int VEC = Elem<T>::VEC;
     constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
     const int G = 1 << gshift;
-    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> gshift;
-    const int gl = (int)(gtid & (G - 1));
+    const int gl = threadIdx.x & (G - 1);
+    const int gi = threadIdx.x >> gshift, groups = 256 >> gshift;
     const int64_t items = B * (int64_t)kchunks * N;
+    const int64_t nblocks = (items + SEG_BLOCK - 1) / SEG_BLOCK;
 
-    for (int64_t item = gtid >> gshift; item < items; item += ngroups) {
+    // A workgroup visits SEG_BLOCK CONSECUTIVE items (= consecutive output rows) at a time, its lane groups interleaved
+    // over them: what it stores is one contiguous run (128 KiB for 512-B rows), written front to back. Grid-striding the
+    // items instead (each workgroup round 4 KiB here, the next one a whole grid away) ran 2-4 % slower at config 2 and
+    // is the pattern that loses 10-25 % in a plain copy / fill (tools/micro/store_sweep.hip, seg_store.hip, round 3).
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x)
+    for (int64_t item = blk * SEG_BLOCK + gi, iend = (blk + 1) * SEG_BLOCK < items ? (blk + 1) * SEG_BLOCK : items; item < iend;
+         item += groups) {
         const int64_t n = item % N;
         const int64_t bc = item / N;
         const int chunk = (int)(bc % kchunks);
@@ -308,8 +315,7 @@ int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void
         const int G = 1 << gshift;
         const int kchunks = (int)gnnops_cdiv(vecs, G);
         const int64_t items = B * kchunks * N;
-        const int64_t groups_per_block = 256 >> gshift;
-        int grid = gnnops_grid_cap(gnnops_cdiv(items, groups_per_block), 256 * 64);
+        int grid = gnnops_grid_cap(gnnops_cdiv(items, SEG_BLOCK), 256 * 16);
         // hubs (hub.h) are set aside when the caller brought the workspace for them: plan form, one matrix
         constexpr bool IS_ARG_R = (R == GNNOPS_MIN || R == GNNOPS_MAX);
         const bool want_arg = IS_ARG_R;

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNNOPS_LIB_PATH: another build of the same ABI (A/B timing of two builds on one box: tools/time_partition.py)
 LIB_PATH = os.environ.get("GNNOPS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libgnnops.so")
 
+ABI_VERSION = 2   # GNNOPS_ABI_VERSION of include/gnnops.h
 F32, F16, BF16 = 0, 1, 2
 SUM, MEAN, MIN, MAX, MUL = 0, 1, 2, 3, 4
 OK, EINVAL, EWORKSPACE, ELAUNCH, EUNSUPPORTED = 0, 1, 2, 3, 4  # status codes of include/gnnops.h
@@ -42,7 +43,7 @@ SIGNATURES = {
     "gnnops_scatter_elementwise_workspace_bytes": (_sz, [_i64, _i64, _i64, _ci, _ci]),
     "gnnops_scatter_elementwise": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
     "gnnops_scatter_elementwise_ix": (_ci, [_vp, _vp, _ci, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
-    "gnnops_narrow_index": (_ci, [_vp, _vp, _i64, _ci, _vp]),
+    "gnnops_narrow_index": (_ci, [_vp, _vp, _i64, _ci, _i64, _vp]),
     "gnnops_index_select": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
     "gnnops_index_select_planned": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
     "gnnops_gather": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
@@ -114,6 +115,8 @@ def load():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if L.gnnops_version() != ABI_VERSION:     # GNNOPS_LIB_PATH may point at another build: it must speak this binding's ABI
+        raise ImportError(f"gnnops: {LIB_PATH} reports ABI version {L.gnnops_version()}, this binding needs {ABI_VERSION}; rebuild it")
     _lib = L
     return L
 

@@ -1,222 +1,341 @@
-"""Opt-in ATen overrides: route the native ops the reference scripts call by name to the HIP kernels.
+"""Opt-in ATen routes: the native ops the reference scripts call by name reach the HIP kernels — and every operand
+the kernels do not take reaches the STOCK kernel it always reached.
 
 Reference call sites: torch.index_select (op_bm_scripts/benchmark_native_index_select.py:14),
 Tensor.index_add_ (benchmark_native_index_add_.py:15), torch.gather (benchmark_native_gather.py:16),
 Tensor.scatter_add_ (benchmark_scatter_add.py:24), torch.index_add
 (benchmark_fused_index_add_reduce.py:13), torch.sort (benchmark_native_sort.py:29), torch.addmm / torch.matmul
 (benchmark_native_addmm.py:15, benchmark_native_matmul.py:15), Tensor.scatter_(reduce="multiply")
-(benchmark_scatter_multiply.py:44), and — on the SparseCUDA key — torch.sparse.mm with a dense or a sparse right operand
-(benchmark_sparse_spmm.py:13, benchmark_sparse_spspmm.py:13) and Tensor.coalesce() (benchmark_sparse_coalesce.py:41).
+(benchmark_scatter_multiply.py:44), `torch.transpose(matA, 0, 1).contiguous()` (benchmark_sparse_transpose.py:13-16:
+`contiguous` of a strided view is `clone(memory_format=contiguous_format)`), and — on the SparseCUDA key —
+torch.sparse.mm with a dense or a sparse right operand (benchmark_sparse_spmm.py:13, benchmark_sparse_spspmm.py:13) and
+Tensor.coalesce() (benchmark_sparse_coalesce.py:41). The same process also runs the reference's OTHER callers of these
+ATen ops (graph_benchmark/profile/OpProfiler.py:259-322 train + eval loops over graph_benchmark/models/ptg_models.py:
+nn.Linear in fp32 / fp64, integer `degree` scatters, sorts of int64 matrices, ...), so the seam has ONE mechanism:
 
-Two seams are not ATen kernels: `Tensor.contiguous()` of a 2-D transposed view (benchmark_sparse_transpose.py:13-16; see
-_patch_contiguous) and the `@torch.jit.script` text of the two "fused" scripts (gnnops/jit.py).
+    stock  = torch.library.get_kernel("aten::<op>", key)        # the kernel PyTorch itself would run, captured first
+    kernel = lambda keyset, *a, **kw: hip(*a, **kw) if accepts(*a, **kw) else stock.call_boxed(keyset, *a, **kw)
+    Library("aten", "IMPL").impl("<op>", kernel, key, with_keyset=True)
 
-ROCm builds of PyTorch register device kernels under the "CUDA" dispatch key, so overriding that key is
-what makes ``device="cuda"`` script text reach our kernels. ``install()`` is reversible: ``uninstall()``
-drops the Library object and the stock kernels come back. Inputs the kernels do not cover raise
-NotImplementedError rather than silently running something else.
+`accepts` is a pure predicate over (device, dtype, layout, rank, contiguity, scalar arguments) — one per route, below —
+that says exactly what the gfx950 kernel behind the route takes; anything else is handed, untouched, to the captured
+stock kernel (bit-for-bit PyTorch's own result, errors included). A route's HIP side may still meet a case only the
+kernel can judge (`NotImplementedError` from an argument guard or an EUNSUPPORTED status, both raised before anything is
+written): that also falls through. ROCm builds of PyTorch register device kernels under the "CUDA" dispatch key, so
+routing that key is what makes ``device="cuda"`` script text reach our kernels. ``install()`` is reversible:
+``uninstall()`` drops the Library object and the stock kernels are the registered ones again. Routes sit BELOW autograd
+(PyTorch has already recorded the op's own derivative formula), so a train step through routed ops is differentiated
+by PyTorch as always.
+
+The one seam that is not an ATen kernel is the `@torch.jit.script` text of the two "fused" scripts: a graph rewrite
+(gnnops/jit.py) — no single operator sees the index_select -> sum chain.
 """
 import torch
 
 from . import ops
 
 _library = None
-_orig_contiguous = None
-routed_ops = set()   # names overridden by the last install()
+routed_ops = set()   # names routed by the last install()
+stats = {}           # route name -> [calls that ran the HIP kernel, calls handed to the stock kernel]
+
+_FLOATS = (torch.float32, torch.float16, torch.bfloat16)
+_SORT_DTYPES = (torch.float32, torch.float16, torch.bfloat16, torch.int32, torch.int64, torch.float64)
+_SORT_1D_ONLY = (torch.int64, torch.float64)
 
 
-def _patch_contiguous():
-    """`torch.transpose(matA, 0, 1).contiguous()` (benchmark_sparse_transpose.py:13-16): `contiguous` is a composite op
-    (clone -> empty_like + copy_), and a Python kernel on the CUDA key cannot hand the cases it does not want back to
-    the stock `copy_` it replaced. So the seam is the METHOD: `Tensor.contiguous` gets a wrapper that sends a 2-D
-    transposed view of a dense row-major device matrix through the LDS tile transpose (csrc/sparse.hip) and leaves
-    every other call to the original method. Reversible (uninstall())."""
-    global _orig_contiguous
-    if _orig_contiguous is not None:
-        return
-    _orig_contiguous = torch.Tensor.contiguous
-
-    def contiguous(self, *args, **kwargs):
-        if (not args and not kwargs and self.dim() == 2 and self.is_cuda and not self.is_contiguous()
-                and self.stride(0) == 1 and self.stride(1) == self.size(0) and self.size(0) > 1 and self.size(1) > 1
-                and self.element_size() in (1, 2, 4, 8) and not self.is_complex()
-                and not (torch.is_grad_enabled() and self.requires_grad)
-                and not self.is_sparse and self.layout == torch.strided):
-            from . import sparse
-
-            return sparse.transpose_contiguous(self.t())     # self.t() is the dense row-major [C, R] matrix
-        return _orig_contiguous(self, *args, **kwargs)
-
-    torch.Tensor.contiguous = contiguous
+# ---- what the kernels take (pure predicates; no device work, no allocation) ---------------------------------------
+def _dense(t):
+    return (isinstance(t, torch.Tensor) and t.is_cuda and t.layout == torch.strided and not t.is_complex()
+            and not t.is_quantized and not t.is_conj() and not t.is_neg())
 
 
-def _unpatch_contiguous():
-    global _orig_contiguous
-    if _orig_contiguous is not None:
-        torch.Tensor.contiguous = _orig_contiguous
-        _orig_contiguous = None
+def _copyable(t):
+    return _dense(t) and t.element_size() in (1, 2, 4, 8)
+
+
+def _same_device(*ts):
+    return all(t.device == ts[0].device for t in ts)
+
+
+def _dim_ok(dim, ndim):
+    return isinstance(dim, int) and ndim >= 1 and -ndim <= dim < ndim
+
+
+def accepts_index_select(self, dim, index):
+    return (_copyable(self) and _dense(index) and _same_device(self, index) and _dim_ok(dim, self.dim())
+            and index.dim() == 1 and index.dtype in (torch.int64, torch.int32) and self.is_contiguous()
+            and self.numel() > 0 and index.numel() > 0)
+
+
+def accepts_gather(self, dim, index, sparse_grad=False):
+    if not (_copyable(self) and _dense(index) and _same_device(self, index) and _dim_ok(dim, self.dim())
+            and index.dim() == self.dim() and index.dtype == torch.int64 and self.is_contiguous() and index.is_contiguous()
+            and self.numel() > 0 and index.numel() > 0):
+        return False
+    d = dim % self.dim()
+    return all(index.size(k) == self.size(k) for k in range(self.dim()) if k != d)
+
+
+def accepts_index_add(self, dim, index, source, alpha=1):
+    if not (_dense(self) and _dense(source) and _dense(index) and _same_device(self, index, source)
+            and self.dtype in _FLOATS and source.dtype == self.dtype and _is_one(alpha) and _dim_ok(dim, self.dim())
+            and source.dim() == self.dim() and index.dim() == 1 and index.dtype in (torch.int64, torch.int32)
+            and self.is_contiguous() and source.is_contiguous() and self.numel() > 0 and source.numel() > 0):
+        return False
+    d = dim % self.dim()
+    return (index.numel() == source.size(d)
+            and all(source.size(k) == self.size(k) for k in range(self.dim()) if k != d))
+
+
+def accepts_scatter(self, dim, index, src):
+    if not (_dense(self) and _dense(src) and _dense(index) and _same_device(self, index, src)
+            and self.dtype in _FLOATS and isinstance(src, torch.Tensor) and src.dtype == self.dtype
+            and _dim_ok(dim, self.dim()) and index.dtype == torch.int64
+            and index.dim() == self.dim() and src.dim() == self.dim() and self.is_contiguous()
+            and self.numel() > 0 and index.numel() > 0):
+        return False
+    d = dim % self.dim()
+    return (all(index.size(k) == self.size(k) for k in range(self.dim()) if k != d)
+            and all(index.size(k) <= src.size(k) for k in range(self.dim())))
+
+
+def accepts_scatter_reduce(self, dim, index, src, *, reduce):
+    return reduce in ("add", "multiply") and accepts_scatter(self, dim, index, src)
+
+
+def accepts_sort(self, dim=-1, descending=False, *, stable=None):
+    if not (_dense(self) and self.dtype in _SORT_DTYPES and _dim_ok(dim, self.dim()) and self.is_contiguous()
+            and self.numel() > 0):
+        return False
+    return self.dtype not in _SORT_1D_ONLY or self.numel() == self.size(dim)
+
+
+def _is_one(x):
+    return isinstance(x, (int, float)) and not isinstance(x, bool) and x == 1
+
+
+def accepts_mm(self, mat2):
+    return (_dense(self) and _dense(mat2) and _same_device(self, mat2) and self.dtype in _FLOATS and mat2.dtype == self.dtype
+            and self.dim() == 2 and mat2.dim() == 2 and self.size(1) == mat2.size(0) and self.is_contiguous()
+            and mat2.is_contiguous() and self.numel() > 0 and mat2.numel() > 0)
+
+
+def accepts_addmm(self, mat1, mat2, *, beta=1, alpha=1):
+    if not (_is_one(beta) and _is_one(alpha) and _dense(self) and accepts_mm(mat1, mat2) and _same_device(self, mat1)
+            and self.dtype == mat1.dtype and self.dim() in (1, 2) and self.is_contiguous()):
+        return False
+    M, N = mat1.size(0), mat2.size(1)
+    shape = (1,) * (2 - self.dim()) + tuple(self.shape)
+    return shape[0] in (1, M) and shape[1] in (1, N)
+
+
+def accepts_clone(self, *, memory_format=None):
+    """`m.transpose(0, 1).contiguous()` of a dense row-major 2-D matrix: the LDS tile transpose (csrc/sparse.hip)."""
+    return (memory_format == torch.contiguous_format and _copyable(self) and self.dim() == 2 and self.size(0) > 1
+            and self.size(1) > 1 and self.stride(0) == 1 and self.stride(1) == self.size(0))
+
+
+def _coo2(t, floats=True):
+    return (isinstance(t, torch.Tensor) and t.is_cuda and t.layout == torch.sparse_coo and t.dim() == 2
+            and t.sparse_dim() == 2 and t.dense_dim() == 0 and (t.dtype in _FLOATS or not floats) and t._nnz() > 0)
+
+
+def accepts_sparse_dense(sparse, dense):
+    return (_coo2(sparse) and _dense(dense) and dense.dim() == 2 and dense.dtype == sparse.dtype and dense.is_contiguous()
+            and sparse.size(1) == dense.size(0) and dense.numel() > 0 and _same_device(sparse, dense))
+
+
+def accepts_sparse_addmm(self, mat1, mat2, *, beta=1, alpha=1):
+    # torch.sparse.mm(S, D) lowers to addmm(zeros, S, D, beta=0, alpha=1) on the sparse key; nothing else is ours
+    return (isinstance(beta, (int, float)) and beta == 0 and _is_one(alpha) and _dense(self)
+            and accepts_sparse_dense(mat1, mat2))
+
+
+def accepts_sparse_sparse(self, other):
+    return _coo2(self) and _coo2(other) and self.dtype == other.dtype and self.size(1) == other.size(0) and _same_device(self, other)
+
+
+def accepts_coalesce(self):
+    return (isinstance(self, torch.Tensor) and self.is_cuda and self.layout == torch.sparse_coo and self.sparse_dim() == 2
+            and self.dim() == 2 and self.dtype in _FLOATS and self._nnz() > 0 and not self.is_coalesced())
+
+
+# ---- the HIP side of each route --------------------------------------------------------------------------------
+def _hip_index_select(self, dim, index):
+    return ops.index_select(self, dim, index)
+
+
+def _hip_gather(self, dim, index, sparse_grad=False):
+    return ops.gather(self, dim, index)
+
+
+def _hip_index_add_(self, dim, index, source, alpha=1):
+    return ops.index_add_(self, dim, index, source)
+
+
+def _hip_index_add(self, dim, index, source, alpha=1):
+    return ops.index_add_(_fresh_copy(self), dim, index, source)
+
+
+def _hip_scatter_add_(self, dim, index, src):
+    return ops.scatter_add_(self, dim, index, src)
+
+
+def _hip_scatter_add(self, dim, index, src):
+    return ops.scatter_add_(_fresh_copy(self), dim, index, src)
+
+
+def _hip_scatter_reduce_(self, dim, index, src, *, reduce):
+    # Tensor.scatter_(dim, index, src, reduce="add" | "multiply") (benchmark_scatter_multiply.py:44)
+    if reduce == "add":
+        return ops.scatter_add_(self, dim, index, src)
+    return ops.scatter_reduce_mul_(self, dim, index, src)
+
+
+def _hip_sort_stable(self, *, stable, dim=-1, descending=False):
+    from . import sparse
+
+    return sparse.sort(self, dim=dim, descending=descending, stable=True)     # the radix engine is always stable
+
+
+def _hip_sort(self, dim=-1, descending=False):
+    from . import sparse
+
+    return sparse.sort(self, dim=dim, descending=descending)
+
+
+def _hip_addmm(self, mat1, mat2, *, beta=1, alpha=1):
+    return ops.addmm(self, mat1, mat2)
+
+
+def _hip_mm(self, mat2):
+    return ops.matmul(self, mat2)
+
+
+def _hip_clone(self, *, memory_format=None):
+    from . import sparse
+
+    return sparse.transpose_contiguous(self.t())     # self.t() is the dense row-major [C, R] matrix
+
+
+def _hip_sparse_mm(sparse, dense):
+    from . import sparse as sp
+
+    return sp.sparse_mm(sparse, dense)
+
+
+def _hip_sparse_addmm(self, mat1, mat2, *, beta=1, alpha=1):
+    from . import sparse as sp
+
+    return sp.sparse_mm(mat1, mat2)
+
+
+def _hip_coalesce(self):
+    from . import sparse as sp
+
+    return sp.coalesce_sparse_tensor(self)
+
+
+def _fresh_copy(t):
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    out.copy_(t)
+    return out
+
+
+def _accepts_sort_stable(self, *, stable, dim=-1, descending=False):
+    return accepts_sort(self, dim, descending, stable=stable)
+
+
+# (operator, dispatch key, accepts, hip). The sparse routes are optional: a build that refuses them keeps its kernels.
+ROUTES = (
+    ("index_select", "CUDA", accepts_index_select, _hip_index_select),
+    ("gather", "CUDA", accepts_gather, _hip_gather),
+    ("index_add_", "CUDA", accepts_index_add, _hip_index_add_),
+    ("index_add", "CUDA", accepts_index_add, _hip_index_add),
+    ("scatter_add_", "CUDA", accepts_scatter, _hip_scatter_add_),
+    ("scatter_add", "CUDA", accepts_scatter, _hip_scatter_add),
+    ("scatter_.reduce", "CUDA", accepts_scatter_reduce, _hip_scatter_reduce_),
+    ("sort.stable", "CUDA", _accepts_sort_stable, _hip_sort_stable),
+    ("sort", "CUDA", accepts_sort, _hip_sort),
+    ("addmm", "CUDA", accepts_addmm, _hip_addmm),
+    ("mm", "CUDA", accepts_mm, _hip_mm),
+    ("clone", "CUDA", accepts_clone, _hip_clone),
+    ("_sparse_mm", "SparseCUDA", accepts_sparse_dense, _hip_sparse_mm),
+    ("addmm", "SparseCUDA", accepts_sparse_addmm, _hip_sparse_addmm),
+    ("_sparse_sparse_matmul", "SparseCUDA", accepts_sparse_sparse, _hip_sparse_mm),
+    ("_coalesce", "SparseCUDA", accepts_coalesce, _hip_coalesce),
+)
+
+
+def _route_name(op, key):
+    return op if key == "CUDA" else f"{op}@{key}"
+
+
+def _make_kernel(name, accepts, hip, stock):
+    count = stats.setdefault(name, [0, 0])
+
+    def kernel(keyset, *args, **kwargs):
+        if accepts(*args, **kwargs):
+            try:
+                # below PyTorch's Autograd key: the op's own derivative is already recorded, the raw kernel is what runs
+                with torch.no_grad():
+                    out = hip(*args, **kwargs)
+                count[0] += 1
+                return out
+            except NotImplementedError:
+                pass            # an argument guard / EUNSUPPORTED status: raised before anything was written
+        count[1] += 1
+        return stock.call_boxed(keyset, *args, **kwargs)
+
+    kernel.__name__ = "gnnops_route_" + name.replace(".", "_").replace("@", "_")
+    return kernel
 
 
 def installed():
     return _library is not None
 
 
-def install():
-    global _library
+def install(key="CUDA", sparse_key="SparseCUDA"):
+    """Route the ops of ROUTES. `key` / `sparse_key` exist for the CPU suite, which exercises the fall-through
+    mechanism itself on the CPU keys (where no operand is ever accepted: the predicates require device tensors)."""
+    global _library, routed_ops
     if _library is not None:
         return
+    import warnings
+
     lib = torch.library.Library("aten", "IMPL")
     routed = set()
-
-    def below_autograd(fn):
-        """A kernel registered on the CUDA / SparseCUDA key runs BELOW PyTorch's Autograd key: the stock derivative
-        formulas of the ATen op have already been recorded, so the raw kernels are what must run here (their own
-        "operand requires grad" refusal does not apply)."""
-        def kernel(*args, **kwargs):
-            with torch.no_grad():
-                return fn(*args, **kwargs)
-        kernel.__name__ = fn.__name__
-        return kernel
-
-    _impl = lib.impl
-
-    def impl(name, fn, key):
-        _impl(name, below_autograd(fn), key)
-
-    def index_select(self, dim, index):
-        return ops.index_select(self, dim, index)
-
-    def gather(self, dim, index, sparse_grad=False):
-        return ops.gather(self, dim, index)
-
-    def index_add_(self, dim, index, source, alpha=1):
-        return ops.index_add_(self, dim, index, source, alpha)
-
-    def index_add(self, dim, index, source, alpha=1):
-        return ops.index_add_(self.clone(), dim, index, source, alpha)
-
-    def scatter_add_(self, dim, index, src):
-        return ops.scatter_add_(self, dim, index, src)
-
-    def scatter_add(self, dim, index, src):
-        return ops.scatter_add_(self.clone(), dim, index, src)
-
-    def sort_stable(self, *, stable, dim=-1, descending=False):
-        from . import sparse
-
-        return sparse.sort(self, dim=dim, descending=descending, stable=bool(stable))
-
-    def sort_default(self, dim=-1, descending=False):
-        from . import sparse
-
-        return sparse.sort(self, dim=dim, descending=descending)
-
-    def addmm(self, mat1, mat2, *, beta=1, alpha=1):
-        return ops.addmm(self, mat1, mat2, beta=beta, alpha=alpha)
-
-    def mm(self, mat2):
-        return ops.matmul(self, mat2)
-
-    def scatter_reduce_(self, dim, index, src, *, reduce):
-        # Tensor.scatter_(dim, index, src, reduce="add" | "multiply") (benchmark_scatter_multiply.py:44)
-        if reduce == "add":
-            return ops.scatter_add_(self, dim, index, src)
-        if reduce == "multiply":
-            return ops.scatter_reduce_mul_(self, dim, index, src)
-        raise NotImplementedError(f"gnnops: scatter_(reduce={reduce!r}) is not supported")
-
-    def sparse_mm(sparse, dense):
-        from . import sparse as sp
-
-        return sp.sparse_mm(sparse, dense)
-
-    def sparse_coalesce(self):
-        from . import sparse as sp
-
-        return sp.coalesce_sparse_tensor(self)
-
-    impl("scatter_.reduce", scatter_reduce_, "CUDA")
-    routed.update({"scatter_.reduce"})
-    # sparse COO operands dispatch on the SparseCUDA key (torch.sparse.mm, Tensor.coalesce()); optional: a build
-    # that refuses these registrations keeps its stock kernels and gnnops.sparse_mm / coalesce_sparse_tensor stay
-    # available by name
-    def sparse_addmm(self, mat1, mat2, *, beta=1, alpha=1):
-        # torch.sparse.mm(S, D) lowers to addmm(zeros, S, D, beta=0, alpha=1) on the sparse key
-        from . import sparse as sp
-
-        prod = sp.sparse_mm(mat1, mat2)
-        if alpha != 1:
-            prod = prod * alpha
-        return prod if beta == 0 else prod + beta * self
-
-    for name, fn in (("_sparse_mm", sparse_mm), ("addmm", sparse_addmm), ("_sparse_sparse_matmul", sparse_mm),
-                     ("_coalesce", sparse_coalesce)):
-        try:
-            impl(name, fn, "SparseCUDA")
-            routed.add(name + "@SparseCUDA")
-        except Exception:  # pragma: no cover - depends on the torch build
-            pass
-    impl("sort.stable", sort_stable, "CUDA")
-    impl("sort", sort_default, "CUDA")
-    impl("addmm", addmm, "CUDA")
-    impl("mm", mm, "CUDA")
-    impl("index_select", index_select, "CUDA")
-    impl("gather", gather, "CUDA")
-    impl("index_add_", index_add_, "CUDA")
-    impl("index_add", index_add, "CUDA")
-    impl("scatter_add_", scatter_add_, "CUDA")
-    impl("scatter_add", scatter_add, "CUDA")
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message="(?s).*Overriding a previously registered kernel.*")   # that is the point
+        for op, route_key, accepts, hip in ROUTES:
+            real_key = key if route_key == "CUDA" else sparse_key
+            name = _route_name(op, route_key)
+            try:
+                stock = torch.library.get_kernel("aten::" + op, real_key)     # captured BEFORE the route is registered
+                lib.impl(op, _make_kernel(name, accepts, hip, stock), real_key, with_keyset=True)
+                routed.add(name)
+            except Exception:  # pragma: no cover - depends on the torch build
+                if route_key == "CUDA":
+                    lib._destroy()
+                    raise
     _library = lib
-    _patch_contiguous()
     from . import jit
 
     jit.install_script_hook()
-    global routed_ops
-    routed_ops = routed | {"index_select", "gather", "index_add_", "index_add", "scatter_add_", "scatter_add", "sort",
-                           "sort.stable", "addmm", "mm", "Tensor.contiguous (2-D transposed view)",
-                           "torch.jit.script (index_select -> sum, index_add -> index_select -> sum(dim) rewritten)"}
+    routed_ops = routed | {"torch.jit.script (index_select -> sum, index_add -> index_select -> sum(dim) rewritten)"}
 
 
 def uninstall():
-    global _library
+    global _library, routed_ops
     if _library is not None:
         _library._destroy()
         _library = None
-    _unpatch_contiguous()
+    routed_ops = set()
     from . import jit
 
     jit.uninstall_script_hook()
-_orig_contiguous = None
-routed_ops = set()   # names overridden by the last install()
 
 
-def _patch_contiguous():
-    """`torch.transpose(matA, 0, 1).contiguous()` (benchmark_sparse_transpose.py:13-16): `contiguous` is a composite op
-    (clone -> empty_like + copy_), and a Python kernel on the CUDA key cannot hand the cases it does not want back to
-    the stock `copy_` it replaced. So the seam is the METHOD: `Tensor.contiguous` gets a wrapper that sends a 2-D
-    transposed view of a dense row-major device matrix through the LDS tile transpose (csrc/sparse.hip) and leaves
-    every other call to the original method. Reversible (uninstall())."""
-    global _orig_contiguous
-    if _orig_contiguous is not None:
-        return
-    _orig_contiguous = torch.Tensor.contiguous
-
-    def contiguous(self, *args, **kwargs):
-        if (not args and not kwargs and self.dim() == 2 and self.is_cuda and not self.is_contiguous()
-                and self.stride(0) == 1 and self.stride(1) == self.size(0) and self.size(0) > 1 and self.size(1) > 1
-                and self.element_size() in (1, 2, 4, 8) and not self.is_complex()
-                and not (torch.is_grad_enabled() and self.requires_grad)
-                and not self.is_sparse and self.layout == torch.strided):
-            from . import sparse
-
-            return sparse.transpose_contiguous(self.t())     # self.t() is the dense row-major [C, R] matrix
-        return _orig_contiguous(self, *args, **kwargs)
-
-    torch.Tensor.contiguous = contiguous
-
-
-def _unpatch_contiguous():
-    global _orig_contiguous
-    if _orig_contiguous is not None:
-        torch.Tensor.contiguous = _orig_contiguous
-        _orig_contiguous = None
+def reset_stats():
+    for v in stats.values():
+        v[0] = v[1] = 0

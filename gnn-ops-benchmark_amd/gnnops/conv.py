@@ -240,7 +240,7 @@ class CGConv(_Layer):
         self.lin_f = torch.nn.Linear(sum(self._ch) + dim, self._ch[1], bias=bias)
         self.lin_s = torch.nn.Linear(sum(self._ch) + dim, self._ch[1], bias=bias)
         self.bn = torch.nn.BatchNorm1d(self._ch[1]) if batch_norm else None
-        self._pk_dst, self._pk_src, self._pk_edge = _Packed(), _Packed(), _Packed()
+        self._pk_both, self._pk_dst, self._pk_src, self._pk_edge = _Packed(), _Packed(), _Packed(), _Packed()
         self._freeze()
 
     def forward(self, x, edge_index, edge_attr=None):
@@ -255,7 +255,7 @@ class CGConv(_Layer):
         src_blocks = [(Wf[:, c_dst:c_dst + c_src], None), (Ws[:, c_dst:c_dst + c_src], None)]  # -> q = [f | s]
         n_dst = x_dst.size(0)
         if x_src is x_dst:   # one product for both sides: [p | q] = x @ [W_f,i | W_s,i | W_f,j | W_s,j]
-            pq = _dense(x_dst.contiguous(), self._pk_dst.get(params, dst_blocks + src_blocks))
+            pq = _dense(x_dst.contiguous(), self._pk_both.get(params, dst_blocks + src_blocks))   # its own cache: 4K columns, not 2K
             p, q = pq[:, :2 * K], pq[:, 2 * K:]
         else:
             p = _dense(x_dst.contiguous(), self._pk_dst.get(params, dst_blocks))

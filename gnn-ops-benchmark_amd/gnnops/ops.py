@@ -223,19 +223,20 @@ def _narrowed(index, full, bound):
     if not _plan_cache_enabled or bound >= 2 ** 31 or _version_of(index) is None:
         return full, 8
     key = id(index)
+    what = (bound, tuple(full.shape))     # an index that broadcasts ([1, K]) can meet a src of another E: the copy is per SHAPE
     hit = _narrow_cache.get(key)
-    if hit is None or hit[0]() is not index or hit[1] != index._version or hit[2] != bound:
+    if hit is None or hit[0]() is not index or hit[1] != index._version or hit[2] != what:
         if len(_narrow_cache) >= _NARROW_CACHE_MAX:
             _narrow_cache.pop(next(iter(_narrow_cache)))
-        _narrow_cache[key] = [weakref.ref(index, lambda _r, key=key: _narrow_cache.pop(key, None)), index._version, bound, None]
+        _narrow_cache[key] = [weakref.ref(index, lambda _r, key=key: _narrow_cache.pop(key, None)), index._version, what, None]
         return full, 8                                  # first sighting: nothing to amortise yet
     if hit[3] == "unsupported":
         return full, 8
     if hit[3] is None:
-        nbytes = 2 if bound <= 65536 else 4
+        nbytes = 2 if bound <= 65535 else 4             # 0xFFFF / -1 mark ids outside [0, bound): never a valid id
         narrow = torch.empty(full.shape, dtype=torch.int16 if nbytes == 2 else torch.int32, device=full.device)
         with torch.cuda.device(full.device):
-            check(_lib.load().gnnops_narrow_index(full.data_ptr(), narrow.data_ptr(), full.numel(), nbytes, _stream()), "narrow_index")
+            check(_lib.load().gnnops_narrow_index(full.data_ptr(), narrow.data_ptr(), full.numel(), nbytes, bound, _stream()), "narrow_index")
         hit[3] = (narrow, nbytes)
     return hit[3]
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNNOPS_ABI_VERSION 1
+#define GNNOPS_ABI_VERSION 2   /* 2: gnnops_narrow_index takes the id bound; round-2 exports (layers, spline, cluster) */
 
 enum gnnops_status {
     GNNOPS_OK = 0,
@@ -180,8 +180,9 @@ int gnnops_scatter_elementwise(const void* src, const int64_t* index, void* out,
 int gnnops_scatter_elementwise_ix(const void* src, const void* index, int index_bytes, void* out, int64_t* arg_out,
                                   int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
                                   void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
-/* out[i] = (int32 / uint16) index[i], i < n; out_bytes 4 or 2. Every entry must fit. */
-int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_bytes, gnnops_stream_t stream);
+/* out[i] = (int32 / uint16) index[i], i < n, for ids in [0, bound); an id outside becomes all ones (-1 / 0xFFFF — never a valid
+ * id: bound <= 65535 for out_bytes 2, < 2^31 for 4), which the element kernels drop as they drop it in the int64 index. */
+int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_bytes, int64_t bound, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch.index_select (benchmark_native_index_select.py:12-15; also the first half of
@@ -292,7 +293,8 @@ int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* ou
                  int64_t M, int64_t N, int64_t K, int dtype,
                  void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 /* The same with a row pitch for `input` (elements): ld_input = N is gnnops_addmm; ld_input = 0 adds ONE row [N] to every
- * output row — the bias of a Linear layer (app_bm/groq_script.py:75-76 lin_f / lin_s) without materialising [M, N]. */
+ * output row — the bias of a Linear layer (app_bm/groq_script.py:75-76 lin_f / lin_s) without materialising [M, N]. Any other
+ * pitch must be >= N and a multiple of 16 bytes (EINVAL otherwise). */
 int gnnops_addmm_ld(const void* input, int64_t ld_input, const void* mat1, const void* mat2, void* out, int64_t M,
                     int64_t N, int64_t K, int dtype, void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 
@@ -346,7 +348,8 @@ int gnnops_sddmm(const int64_t* rows_a, const int64_t* rows_b, const void* a, co
                  int64_t nnz, int64_t D, int dtype, gnnops_stream_t stream);
 /* Destination-partitioned scatter over the GPUs of a node (BASELINE config 5; gnnops/dist.py): counts[g] = number of
  * positions e with g * rows_per_owner <= index[e] < (g + 1) * rows_per_owner, g < owners <= 64 — what sizes the one
- * exchange of the step (the only value the host reads back). counts: device int64[owners], zeroed here. */
+ * exchange of the step (the only value the host reads back). counts: device int64[owners], zeroed here. An id outside
+ * [0, owners * rows_per_owner) is counted for no owner, so sum(counts) < E tells the caller about it. */
 int gnnops_owner_counts(const int64_t* index, int64_t E, int64_t rows_per_owner, int owners, int64_t* counts,
                         gnnops_stream_t stream);
 size_t gnnops_rowptr_workspace_bytes(int64_t N);

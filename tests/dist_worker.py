@@ -29,7 +29,9 @@ class OracleLocal:
 
     # ---- edge-list form (same contract as HipLocal.owner_counts / route_ready / route_begin / route)
     def owner_counts(self, index, per, world):
-        return torch.from_numpy(np.bincount(index.numpy() // per, minlength=world).astype(np.int64))
+        idx = index.numpy()
+        idx = idx[(idx >= 0) & (idx < per * world)]          # as gnnops_owner_counts: out-of-range ids belong to no owner
+        return torch.from_numpy(np.bincount(idx // per, minlength=world).astype(np.int64))
 
     def route_ready(self, src, lo, hi):
         return src.dtype == torch.float32

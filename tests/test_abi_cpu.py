@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gnnops.h but not exported by libgnnops.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in gnnops/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.gnnops_version() == 1
+    assert lib.gnnops_version() == 2
     assert lib.gnnops_last_error() is not None
 
 

@@ -408,6 +408,35 @@ def test_layer_weights_follow_parameter_updates(conv, ora):
     check(torch.float16)
 
 
+def test_cgconv_tuple_then_tensor_input_on_one_layer(conv, ora):
+    """the fused [p | q] packing (4K columns, x_src is x_dst) and the destination-only packing (2K columns,
+    bipartite call) must not share a cache — a (x_a, x_b) call followed by a plain-tensor call used to reuse the [c, 2K]
+    weight and return an [N, 0] result without an error. Both orders, same layer."""
+    torch.manual_seed(12)
+    layer = conv.CGConv(16, 0).cuda()
+    g = torch.Generator().manual_seed(13)
+    n, e = 120, 900
+    ei = _graph(10, n, e)
+    xa, xb = _rand(g, n, 16), _rand(g, n, 16)
+    P = _np_params(layer)
+
+    def want_bip():
+        src, dst = ei.numpy()
+        z = np.concatenate([_f64(xb)[dst], _f64(xa)[src]], -1)
+        m = ora.sigmoid(z @ P["lin_f.weight"].T + P["lin_f.bias"]) * ora.softplus(z @ P["lin_s.weight"].T + P["lin_s.bias"])
+        return ora.scatter(m, dst, n, "sum") + _f64(xb)
+
+    want_one = ora.cg_conv(_f64(xa), ei.numpy(), P["lin_f.weight"], P["lin_f.bias"], P["lin_s.weight"], P["lin_s.bias"])
+    with torch.no_grad():
+        for _ in range(2):      # tuple -> tensor -> tuple -> tensor
+            got = layer((xa.cuda(), xb.cuda()), ei.cuda())
+            assert got.shape == (n, 16)
+            _close(got, want_bip(), torch.float32, "CGConv bipartite call")
+            got = layer(xa.cuda(), ei.cuda())
+            assert got.shape == (n, 16)
+            _close(got, want_one, torch.float32, "CGConv plain call after a bipartite one")
+
+
 def test_fused_layer_equals_the_unfused_chain_at_scale(conv):
     """E = 5M, N = 1M, D = 64 fp16 (too big for the float64 oracle): the fused CGConv equals the same layer computed the
     propagate way from this package's own index_select / addmm / scatter_add kernels, within fp16 rounding of the chain."""

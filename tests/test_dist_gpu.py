@@ -93,6 +93,23 @@ def test_owner_counts_and_route_match_oracle(local, oracle, E, n_total, D):
     assert own(buf) is buf and np.array_equal(buf.cpu().numpy(), exp)
 
 
+def test_out_of_range_ids_are_noticed_not_misrouted(local):
+    """gnnops_owner_counts used to clamp every id to an owner, so sharded_scatter's "counts do not add up" guard
+    could never fire and an out-of-range edge was shipped (or reduced) into the wrong rows. Now such an id belongs to no
+    owner: the counts fall short of E and the step raises."""
+    src, idx = _inputs(5000, 3000, 16, 17)
+    world, rank, per = 3, 1, 1000
+    bad = idx.clone()
+    bad[7], bad[4000] = -1, 3000
+    counts = local.owner_counts(bad.cuda(), per, world).cpu().tolist()
+    keep = np.ones(5000, bool)
+    keep[[7, 4000]] = False
+    assert counts == np.bincount(idx.numpy()[keep] // per, minlength=world).tolist() and sum(counts) == 4998
+    state = local.route_begin(src.cuda(), bad.cuda(), rank * per, (rank + 1) * per)
+    with pytest.raises(RuntimeError, match="do not add up"):
+        local.route(state, 3000, rank * per, (rank + 1) * per, counts, rank)
+
+
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
 @pytest.mark.parametrize("with_value", [True, False])
 def test_spmm_split_matches_oracle(local, oracle, with_value, dname):

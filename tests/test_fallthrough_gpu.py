@@ -1,0 +1,229 @@
+"""GPU suite: gnnops.install() narrows nothing. SURVEY.md §8(b) "ATen seam": the routes must fall through to the stock
+kernel for unsupported dtypes / ranks / non-contiguous inputs, because the same process runs the reference's OTHER callers
+of these ATen ops (graph_benchmark/profile/OpProfiler.py:259-322 train + eval loops, graph_benchmark/models/ptg_models.py:
+62-78): float64 / integer `mm`, `addmm` with beta / alpha, the integer `degree` scatter idiom, sorts of int64 matrices ...
+
+Every case is computed twice on the device — once before install() (PyTorch's own kernel) and once under it — and must be
+BIT-identical where the call falls through; supported operands must still reach the HIP kernels (aten.stats)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gn():
+    import gnnops
+
+    gnnops.load_library()
+    return gnnops
+
+
+def _unsupported_cases():
+    """name -> (route that must hand it to the stock kernel, thunk)."""
+    g = torch.Generator().manual_seed(77)
+    dev = "cuda"
+    a64, b64 = torch.rand(33, 17, generator=g, dtype=torch.float64).to(dev), torch.rand(17, 9, generator=g, dtype=torch.float64).to(dev)
+    ai, bi = torch.randint(-5, 5, (33, 17), generator=g).to(dev), torch.randint(-5, 5, (17, 9), generator=g).to(dev)
+    a32, b32, c32 = torch.rand(64, 48, generator=g).to(dev), torch.rand(48, 40, generator=g).to(dev), torch.rand(64, 40, generator=g).to(dev)
+    wide = torch.zeros(50, 64, device=dev)
+    idx_full = torch.randint(0, 50, (200, 32), generator=g).to(dev)
+    src32 = torch.rand(200, 32, generator=g).to(dev)
+    deg_index = torch.randint(0, 300, (1, 5000), generator=g).to(dev)
+    m64 = torch.randint(0, 1000, (300, 257), generator=g).to(dev)
+    base = torch.rand(300, 64, generator=g).to(dev)
+    idx = torch.randint(0, 300, (450,), generator=g).to(dev)
+    source = torch.rand(450, 64, generator=g).to(dev)
+    half = torch.rand(64, 48, generator=g).half().to(dev)
+    sp64 = torch.nn.functional.dropout(torch.rand(40, 30, generator=g, dtype=torch.float64), p=0.8).to(dev).to_sparse()
+    d64 = torch.rand(30, 8, generator=g, dtype=torch.float64).to(dev)
+    unc = torch.sparse_coo_tensor(torch.randint(0, 20, (2, 300), generator=g).to(dev), torch.randint(0, 9, (300,), generator=g).to(dev), (20, 20))
+
+    def noncontig_scatter():
+        view = wide.clone()[:, ::2]                                        # a non-contiguous self
+        view.scatter_add_(0, idx_full, src32)
+        return view
+
+    return {
+        "mm float64": ("mm", lambda: torch.mm(a64, b64)),
+        "mm int64": ("mm", lambda: torch.mm(ai, bi)),
+        "mm transposed view": ("mm", lambda: torch.mm(b32.t(), a32.t())),
+        "addmm beta alpha": ("addmm", lambda: torch.addmm(c32, a32, b32, beta=0.5, alpha=2)),
+        "addmm float64": ("addmm", lambda: torch.addmm(torch.ones(9, dtype=torch.float64, device=dev), a64, b64)),
+        "scatter_add_ non-contiguous self": ("scatter_add_", noncontig_scatter),
+        "scatter_add_ int64 src (degree)": ("scatter_add_", lambda: torch.zeros(1, 300, dtype=torch.int64, device=dev).scatter_add_(
+            1, deg_index, torch.ones_like(deg_index))),
+        "scatter_add int64": ("scatter_add", lambda: torch.scatter_add(torch.zeros(1, 300, dtype=torch.int64, device=dev), 1, deg_index,
+                                                                      torch.ones_like(deg_index))),
+        "sort int64 matrix dim 1": ("sort", lambda: torch.sort(m64, dim=1)),
+        "sort int64 matrix dim 0 stable": ("sort.stable", lambda: torch.sort(m64, dim=0, stable=True)),
+        "sort transposed view": ("sort", lambda: torch.sort(a32.t(), dim=1)),
+        "index_add_ alpha=2": ("index_add_", lambda: base.clone().index_add_(0, idx, source, alpha=2)),
+        "index_add float64": ("index_add", lambda: torch.index_add(base.double(), 0, idx, source.double())),
+        "index_select non-contiguous": ("index_select", lambda: torch.index_select(base.t(), 1, idx)),
+        "gather index narrower than input": ("gather", lambda: torch.gather(base, 0, idx[:100].view(-1, 1).expand(100, 7).contiguous())),
+        "scatter_ reduce multiply int": ("scatter_.reduce", lambda: torch.ones(3, 300, dtype=torch.int32, device=dev).scatter_(
+            1, deg_index.expand(3, -1).contiguous(), torch.full((3, 5000), 2, dtype=torch.int32, device=dev), reduce="multiply")),
+        "clone plain": ("clone", lambda: half.clone()),
+        "contiguous of a 3-D permute": ("clone", lambda: torch.rand(8, 6, 4, generator=g).to(dev).permute(2, 0, 1).contiguous()),
+        "sparse.mm float64": ("addmm@SparseCUDA", lambda: torch.sparse.mm(sp64, d64)),
+        "coalesce integer values": ("_coalesce@SparseCUDA", lambda: unc.coalesce().to_dense()),
+    }
+
+
+def _flat(res):
+    return list(res) if isinstance(res, (tuple, list)) else [res]
+
+
+def test_unsupported_operands_get_the_stock_kernel_bit_for_bit(gn):
+    from gnnops import aten
+
+    cases = _unsupported_cases()
+    want = {k: [t.clone() for t in _flat(f())] for k, (_, f) in cases.items()}
+    gn.install()
+    try:
+        for name, (route, f) in cases.items():
+            aten.reset_stats()
+            got = _flat(f())
+            if route in aten.routed_ops:
+                assert aten.stats[route][1] >= 1 and aten.stats[route][0] == 0, (name, route, aten.stats[route])
+            assert len(got) == len(want[name]), name
+            for g_, w_ in zip(got, want[name]):
+                assert g_.dtype == w_.dtype and g_.shape == w_.shape and torch.equal(g_, w_), name
+    finally:
+        gn.uninstall()
+
+
+def test_errors_of_the_stock_kernels_come_through(gn):
+    gn.install()
+    try:
+        with pytest.raises(RuntimeError):
+            torch.mm(torch.rand(3, 4, device="cuda"), torch.rand(5, 6, device="cuda"))
+        with pytest.raises((RuntimeError, IndexError)):
+            torch.index_select(torch.rand(3, 4, device="cuda"), 5, torch.tensor([0], device="cuda"))
+        with pytest.raises(RuntimeError):
+            torch.zeros(3, 4, device="cuda").scatter_add_(0, torch.zeros(2, 4, dtype=torch.int32, device="cuda"), torch.ones(2, 4, device="cuda"))
+    finally:
+        gn.uninstall()
+
+
+def test_supported_operands_still_reach_the_hip_kernels(gn):
+    from gnnops import aten
+
+    g = torch.Generator().manual_seed(78)
+    x = torch.rand(300, 64, generator=g).cuda()
+    idx = torch.randint(0, 300, (450,), generator=g).cuda()
+    src = torch.rand(450, 64, generator=g).cuda()
+    h = torch.rand(96, 64, generator=g).half().cuda()
+    gn.install()
+    try:
+        aten.reset_stats()
+        sel = torch.index_select(x, 0, idx)
+        acc = x.clone().index_add_(0, idx, src)
+        gat = torch.gather(x, 0, idx[:300].view(-1, 1).expand(300, 64).contiguous())
+        sc = torch.zeros(300, 64, device="cuda").scatter_add_(0, idx.view(-1, 1).expand(450, 64), src)
+        v, i = torch.sort(x, dim=1)
+        mm = torch.mm(h, h.t().contiguous())
+        am = torch.addmm(x[:, :48].contiguous(), x, torch.rand(64, 48, generator=g).cuda())
+        tr = x.t().contiguous()
+        hip = {k: c[0] for k, c in aten.stats.items()}
+    finally:
+        gn.uninstall()
+    for name in ("index_select", "index_add_", "gather", "scatter_add_", "sort", "mm", "addmm", "clone"):
+        assert hip[name] >= 1, (name, hip)
+    assert torch.equal(sel, x[idx]) and torch.equal(tr, x.t().clone(memory_format=torch.contiguous_format))
+    assert torch.equal(gat, torch.gather(x, 0, idx[:300].view(-1, 1).expand(300, 64).contiguous()))
+    ev, ei = torch.sort(x, dim=1, stable=True)
+    assert torch.equal(v, ev) and torch.equal(i, ei)
+    torch.testing.assert_close(acc, x.clone().index_add_(0, idx, src), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(sc, torch.zeros(300, 64, device="cuda").index_add_(0, idx, src), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(mm.float(), h.float() @ h.float().t(), rtol=2e-3, atol=2e-2)
+    assert am.shape == (300, 48)
+
+
+def _linear_train_step(dtype):
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8)).to("cuda", dtype)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    g = torch.Generator().manual_seed(12)
+    xs = torch.rand(3, 128, 32, generator=g).to("cuda", dtype)
+    ys = torch.rand(3, 128, 8, generator=g).to("cuda", dtype)
+    losses = []
+    for x, y in zip(xs, ys):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(net(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach().clone())
+    return losses + [p.detach().clone() for p in net.parameters()]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_a_two_layer_linear_train_step_is_unchanged_by_install(gn, dtype):
+    """forward + backward + SGD of nn.Linear layers (addmm / mm on transposed weight views, fp32 and fp64): the routes hand
+    every one of these to the stock kernels, so the installed run equals the un-installed one bit for bit."""
+    want = _linear_train_step(dtype)
+    gn.install()
+    try:
+        got = _linear_train_step(dtype)
+    finally:
+        gn.uninstall()
+    for g_, w_ in zip(got, want):
+        assert torch.equal(g_, w_)
+
+
+def _message_passing_train_step():
+    """A hand-written GCN-like layer in plain torch text: mm (contiguous operands), index_select by source, index_add_ by
+    destination — autograd differentiates the ATen ops; under install() forward AND backward run on the routed kernels."""
+    torch.manual_seed(21)
+    g = torch.Generator().manual_seed(22)
+    N, E, Fin, H = 2000, 12000, 64, 32
+    x = torch.rand(N, Fin, generator=g).cuda()
+    src = torch.randint(0, N, (E,), generator=g).cuda()
+    dst = torch.randint(0, N, (E,), generator=g).cuda()
+    y = torch.rand(N, H, generator=g).cuda()
+    w1 = torch.nn.Parameter((torch.rand(Fin, H, generator=g) - 0.5).cuda())
+    w2 = torch.nn.Parameter((torch.rand(H, H, generator=g) - 0.5).cuda())
+    opt = torch.optim.SGD([w1, w2], lr=0.01)
+    out = []
+    for _ in range(2):
+        opt.zero_grad()
+        h = torch.mm(x, w1)
+        msg = torch.index_select(h, 0, src)
+        agg = torch.zeros(N, H, device="cuda").index_add_(0, dst, msg)
+        h2 = torch.mm(torch.relu(agg), w2)
+        loss = (h2 - y).square().mean()
+        loss.backward()
+        opt.step()
+        out.append(loss.detach().clone())
+    return out + [w1.detach().clone(), w2.detach().clone(), w1.grad.clone(), w2.grad.clone()]
+
+
+def test_a_message_passing_train_step_runs_on_the_routed_kernels(gn):
+    from gnnops import aten
+
+    want = _message_passing_train_step()
+    gn.install()
+    try:
+        aten.reset_stats()
+        got = _message_passing_train_step()
+        hip = {k: c[0] for k, c in aten.stats.items()}
+    finally:
+        gn.uninstall()
+    assert hip["mm"] >= 4 and hip["index_select"] >= 2 and hip["index_add_"] >= 2, hip
+    for g_, w_ in zip(got, want):
+        torch.testing.assert_close(g_, w_, rtol=2e-4, atol=2e-5)
+
+
+def test_install_is_idempotent_and_reversible(gn):
+    from gnnops import aten
+
+    gn.install()
+    gn.install()
+    assert gn.installed() and "mm" in aten.routed_ops
+    gn.uninstall()
+    gn.uninstall()
+    assert not gn.installed() and not aten.routed_ops
+    aten.reset_stats()
+    torch.mm(torch.rand(8, 8, device="cuda"), torch.rand(8, 8, device="cuda"))
+    assert aten.stats["mm"] == [0, 0]

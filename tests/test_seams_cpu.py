@@ -1,4 +1,4 @@
-"""CPU suite: the two seams that are not ATen kernels (gnnops/jit.py, gnnops/aten.py _patch_contiguous).
+"""CPU suite: the TorchScript seam (gnnops/jit.py) and the fall-through mechanism of the ATen routes (gnnops/aten.py).
 
 The reference's "fused" scripts hand `@torch.jit.script` functions to the Timer (op_bm_scripts/
 benchmark_fused_index_select_reduce.py:12-15, benchmark_fused_index_add_reduce.py:12-15); their bodies are restated here
@@ -76,19 +76,75 @@ def test_fuse_applies_to_an_already_scripted_function():
     assert jit.is_fused(jit.fuse(fn))
 
 
-def test_contiguous_patch_is_reversible_and_leaves_cpu_tensors_alone():
+def _workload():
+    """Calls of every routed operator with operands the HIP kernels do not take (here: CPU tensors; on the GPU box
+    tests/test_fallthrough_gpu.py does the same with device tensors of unsupported dtype / layout / arguments)."""
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.rand(6, 4, generator=g, dtype=torch.float64), torch.rand(4, 5, generator=g, dtype=torch.float64)
+    out = [a @ b, torch.addmm(torch.ones(5, dtype=torch.float64), a, b, beta=0.5, alpha=2)]
+    x = torch.zeros(5, 3)
+    x.index_add_(0, torch.tensor([1, 1, 2]), torch.ones(3, 3), alpha=2)
+    out.append(x)
+    out.append(torch.index_add(torch.zeros(5, 3), 0, torch.tensor([4, 0, 0]), torch.ones(3, 3)))
+    m = torch.randint(0, 50, (7, 9), generator=g)
+    out += list(torch.sort(m, dim=1)) + list(torch.sort(m, dim=0, stable=True, descending=True))
+    out.append(torch.zeros(3, 4, dtype=torch.int64).scatter_add_(1, torch.tensor([[0, 0, 1]]), torch.tensor([[1, 2, 3]])))
+    out.append(torch.ones(3, 4).scatter_(1, torch.tensor([[0, 0, 1]]), torch.tensor([[1., 2, 3]]), reduce="multiply"))
+    out.append(torch.index_select(a, 1, torch.tensor([3, 0])))
+    out.append(torch.gather(a, 0, torch.randint(0, 6, (2, 4), generator=g)))
+    out.append(torch.transpose(a, 0, 1).contiguous())
+    s = torch.sparse_coo_tensor(torch.tensor([[0, 0, 1], [1, 1, 2]]), torch.tensor([1., 2, 3]), (3, 3))
+    out += [s.coalesce().to_dense(), torch.sparse.mm(s, s).to_dense(), torch.sparse.mm(s, torch.ones(3, 2))]
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    loss = net(torch.rand(16, 4, generator=g)).square().mean()
+    loss.backward()
+    opt.step()
+    out += [loss.detach()] + [p.detach().clone() for p in net.parameters()]
+    return out
+
+
+def test_routes_hand_everything_they_do_not_accept_to_the_stock_kernel():
+    """The mechanism of gnnops.install(), exercised on the CPU dispatch keys: every route captures the stock kernel with
+    torch.library.get_kernel before it registers, and a call its predicate does not accept (CPU tensors never are) runs
+    that kernel — results bit-identical to an un-routed process, a train step included; uninstall() restores it."""
     from gnnops import aten
 
-    orig = torch.Tensor.contiguous
-    aten._patch_contiguous()
+    want = _workload()
+    assert not aten.installed()
+    aten.install(key="CPU", sparse_key="SparseCPU")
     try:
-        assert torch.Tensor.contiguous is not orig
-        x = torch.arange(12.).view(3, 4)
-        y = torch.transpose(x, 0, 1).contiguous()          # a CPU tensor: the original method
-        assert y.is_contiguous() and torch.equal(y, x.t().clone())
-        assert x.contiguous() is x
-        z = torch.arange(24.).view(2, 3, 4).permute(2, 0, 1).contiguous(memory_format=torch.contiguous_format)
-        assert z.shape == (4, 2, 3) and z.is_contiguous()
+        assert aten.installed()
+        for name in ("mm", "addmm", "index_add_", "index_add", "sort", "sort.stable", "scatter_add_", "scatter_.reduce",
+                     "index_select", "gather", "clone"):
+            assert name in aten.routed_ops, name
+        aten.reset_stats()
+        got = _workload()
+        hip = {k: v[0] for k, v in aten.stats.items()}
+        stock = {k: v[1] for k, v in aten.stats.items()}
+        assert not any(hip.values()), hip                        # nothing here is a device tensor
+        for name in ("mm", "addmm", "index_add_", "index_add", "sort.stable", "scatter_add_", "scatter_.reduce",
+                     "index_select", "gather", "clone"):
+            assert stock[name] >= 1, (name, stock)
     finally:
-        aten._unpatch_contiguous()
-    assert torch.Tensor.contiguous is orig
+        aten.uninstall()
+    assert not aten.installed() and not aten.routed_ops
+    assert len(got) == len(want)
+    for g_, w_ in zip(got, want):
+        assert g_.dtype == w_.dtype and torch.equal(g_, w_)
+    aten.reset_stats()
+    _workload()
+    assert not any(v[0] or v[1] for v in aten.stats.values())   # uninstalled: the routes are gone
+
+
+def test_route_predicates_are_pure_and_reject_what_the_kernels_do_not_take():
+    from gnnops import aten
+
+    f32 = torch.rand(4, 4)
+    idx = torch.tensor([0, 1])
+    assert not aten.accepts_mm(f32, f32) and not aten.accepts_index_select(f32, 0, idx)       # CPU tensors
+    assert not aten.accepts_clone(f32.t(), memory_format=torch.contiguous_format)
+    meta = torch.empty(4, 4, device="meta")
+    assert not aten.accepts_mm(meta, meta) and not aten.accepts_sort(meta, 1)
+    assert aten._is_one(1) and aten._is_one(1.0) and not aten._is_one(2) and not aten._is_one(True)
