@@ -15,7 +15,11 @@ a launcher starts its G ranks itself (torch.distributed.run children, started be
 `value` = algorithmic bytes (E*D*s + E*8 + N*D*s per step, x ranks) / wall time, inputs
 already resident in HBM. The JSON line also carries `roofline` (dominant kernel = the segment-reduce
 launch, timed with events on the launch stream), `cpu_baseline` (the C oracle port on a bounded sample,
-host cores of this box) and per-op numbers for the other config-2 ops.
+host cores of this box) — both at every N, measured on rank 0 — and per-op numbers for the other config-2 ops.
+
+Reading a 1 -> 8 curve: the N=1 headline is config 2 (E=50M per GPU), the N>1 headline config 5's share (E=100M per GPU).
+So that equal per-GPU work can be compared, the N=1 line carries `same_work.c5_share_1gpu` (E=100M, N=10M on one GPU, same
+cold step) and every N>1 line `same_work.c2_share` (E=50M per GPU through the same sharded step).
 """
 import argparse
 import json
@@ -197,10 +201,12 @@ def main():
         result["rehearsal"] = "every rank on cuda:0 over gloo: code-path check only, NOT a measurement"
 
     if dist is not None:
-        def timed_variant(idx, exch, steps, warm=1):
-            nonlocal index, exchange
-            keep = (index, exchange)
+        def timed_variant(idx, exch, steps, warm=1, rows=None):
+            nonlocal index, exchange, src
+            keep = (index, exchange, src)
             index, exchange = idx, exch
+            if rows is not None:
+                src = rows
             try:
                 for _ in range(warm):
                     step()
@@ -211,13 +217,35 @@ def main():
                 fence()
                 el = time.perf_counter() - t1
             finally:
-                index, exchange = keep
+                index, exchange, src = keep
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item()) / steps
-            return {"value": round(job_bytes / el / 1e9, 1), "unit": "GB/s", "ms_per_step": round(el * 1e3, 4)}
+            jb = job_bytes if rows is None else world * algorithmic_bytes("scatter_add", Nloc, rows.size(0), D)
+            return {"value": round(jb / el / 1e9, 1), "unit": "GB/s", "ms_per_step": round(el * 1e3, 4)}
 
         few = max(1, min(args.steps, 3))
+        # the N=1 headline's per-GPU work (config 2: E = 50M per GPU when this workload is c5) through THIS sharded step:
+        # the like-for-like partner of the driver's --gpus 1 line
+        try:
+            half = E // 2
+            result["same_work"] = {"c2_share": dict(
+                timed_variant(index[:half], "sparse", few, rows=src[:half]),
+                note=f"per GPU E={half}, owned rows={Nloc}: the per-GPU work of the --gpus 1 headline (config 2) through the "
+                     f"same sharded step and edge cut")}
+        except Exception as exc:  # noqa: BLE001
+            result["same_work"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # roofline of the dominant kernel and the CPU baseline at this N too (rank 0, its own edges onto its own slab)
+        if rank == 0:
+            try:
+                local_index = index % Nloc
+                result["roofline"] = roofline_leg(torch, gnnops, lib, src, local_index, Nloc, E, D, max(few, 3), False)
+                result["roofline"]["note"] = "rank 0: bucket_reduce_kernel over this rank's E edges folded onto its own slab"
+                del local_index
+            except Exception as exc:  # noqa: BLE001
+                result["roofline"] = {"error": f"{type(exc).__name__}: {exc}"}
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline_leg(D, small=args.workload in ("tiny", "c1"))
         # The legs below are reported beside the headline. A Python-level error in one of them (raised identically on
         # every rank) is recorded instead of losing the headline line.
         # The same per-GPU work on graphs with other edge cuts, beside the headline, never as it:
@@ -251,7 +279,7 @@ def main():
             torch.cuda.empty_cache()
             from gnnops.dist import sharded_spmm
 
-            Mloc, nnz, Dm = 2_000_000, 40_000_000, 256
+            Mloc, nnz, Dm = (2_000_000, 40_000_000, 256) if args.workload in ("c2", "c5") else (max(Nloc // 5, 512), E // 2, 256)
             lo_m = rank * Mloc
             rows_own = torch.randint(lo_m, lo_m + Mloc, (nnz,), generator=gen, device=dev, dtype=torch.int64)
             if world > 1:
@@ -299,13 +327,38 @@ def main():
             torch.cuda.empty_cache()
             result["config4"] = config4_leg(torch, gnnops)
             torch.cuda.empty_cache()
+        if args.workload == "c2" and not args.no_extra_ops:
+            result["same_work"] = {"c5_share_1gpu": same_work_leg(torch, gnnops, dev, "c5", args.steps)}
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_leg(D)
+            result["cpu_baseline"] = cpu_baseline_leg(D, small=args.workload in ("tiny", "c1"))
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def same_work_leg(torch, gnnops, dev, workload, steps):
+    """The cold step of the headline on another workload's per-GPU share, one GPU (what the N>1 lines run per rank, minus
+    the exchange): the like-for-like base of a 1 -> 8 curve whose N>1 points are config 5's share."""
+    Nloc, E, D, _ = WORKLOADS[workload]
+    gen = torch.Generator(device=dev).manual_seed(42)
+    src = torch.rand(E, D, generator=gen, device=dev, dtype=torch.float32)
+    index = torch.randint(0, Nloc, (E,), generator=gen, device=dev, dtype=torch.int64)
+    steps = max(3, min(steps, 10))
+    for _ in range(2):
+        gnnops.scatter_add(src, index, dim=0, dim_size=Nloc)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gnnops.scatter_add(src, index, dim=0, dim_size=Nloc)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    jb = algorithmic_bytes("scatter_add", Nloc, E, D)
+    del src, index
+    torch.cuda.empty_cache()
+    return {"workload": f"{workload}: N={Nloc} E={E} D={D} fp32 on one GPU, cold scatter_add", "value": round(jb / el / 1e9, 1),
+            "unit": "GB/s", "ms_per_step": round(el * 1e3, 4), "pct_of_hbm_peak": round(100 * jb / el / 1e9 / HBM_PEAK_GBS, 2)}
 
 
 def _event_ms(torch, fn, iters):
@@ -545,14 +598,15 @@ def layers_leg(torch, gnnops):
                                              "pct_of_hbm_peak": round(alg_copy / copy / 1e6 / HBM_PEAK_GBS * 100, 2), "bound": "hbm"}}
 
 
-def cpu_baseline_leg(D):
-    """The C oracle port (one core) on a bounded sample of the same workload: N=1M, E=5M, D as configured."""
+def cpu_baseline_leg(D, small=False):
+    """The C oracle port (one core) on a bounded sample of the same workload: N=1M, E=5M, D as configured (small: the
+    rehearsal workloads of the test suite, a tenth of that)."""
     import numpy as np
 
     from oracle import oracle
 
     oracle.lib()
-    Ns, Es = 1_000_000, 5_000_000
+    Ns, Es = (100_000, 500_000) if small else (1_000_000, 5_000_000)
     rng = np.random.default_rng(42)
     src = rng.random((Es, D), dtype=np.float32)
     idx = rng.integers(0, Ns, Es, dtype=np.int64)
@@ -563,15 +617,15 @@ def cpu_baseline_leg(D):
         oracle.scatter_add_rows_f32(src, idx, Ns)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 20:
+        if dt > (1.0 if small else 10.0) or reps >= 20:
             break
     alg = algorithmic_bytes("scatter_add", Ns, Es, D)
     res = {
         "value": round(alg * reps / dt / 1e9, 3),
-        "unit": "GB/s (algorithmic bytes / wall time, on a 1/10 sample of config 2: N=1M E=5M)",
+        "unit": f"GB/s (algorithmic bytes / wall time, on a sample of config 2's shape: N={Ns} E={Es})",
         "cores": 1,
         "kind": "port",
-        "sample": f"oracle/gnnops_oracle.c ora_scatter_add_rows_f32, N={Ns} E={Es} D={D} fp32 (1/10 of config 2), "
+        "sample": f"oracle/gnnops_oracle.c ora_scatter_add_rows_f32, N={Ns} E={Es} D={D} fp32 (config 2 scaled down), "
                   f"{reps} passes in {dt:.1f} s on one of {os.cpu_count()} host cores",
     }
     # Beside it: what the reference's op body executes on CPU tensors (torch_scatter.scatter_add forwards to
@@ -583,7 +637,7 @@ def cpu_baseline_leg(D):
         torch.zeros(Ns, D).index_add_(0, tidx, tsrc)
         t0 = time.perf_counter()
         treps = 0
-        while time.perf_counter() - t0 < 5.0 and treps < 20:
+        while time.perf_counter() - t0 < (1.0 if small else 5.0) and treps < 20:
             torch.zeros(Ns, D).index_add_(0, tidx, tsrc)
             treps += 1
         tdt = time.perf_counter() - t0

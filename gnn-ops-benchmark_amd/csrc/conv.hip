@@ -697,3 +697,118 @@ extern "C" int gnnops_edge_reduce_hubs(int functor, const void* q, int64_t ldq, 
         default: return dispatch<__hip_bfloat16>(functor, multi, a, max_vec, stream);
     }
 }
+
+// ---- backward of the edge pass (training through gnnops.conv; the reference's OpProfiler.py:259-292 profiles a TRAIN loop) ----
+// For sum / mean aggregation the chain rule needs, per edge e = (j -> i), the gradient of the message with respect to the
+// rows it was made from; the sums of those per-edge rows by destination (d p) and by source (d q) are then plain segment
+// reductions over the plans the forward pass already holds. This kernel writes the per-edge rows, in EDGE order (so d w is
+// the rows themselves). Streaming: each edge's operand rows are gathered once, each gradient row stored once.
+namespace {
+template <typename T, int F, bool HAS_W, int VEC>
+__global__ __launch_bounds__(256) void edge_grad_kernel(const T* __restrict__ p, int64_t ldp, const T* __restrict__ q, int64_t ldq,
+                                                        const T* __restrict__ w, int64_t ldw, const T* __restrict__ g, int64_t ldg,
+                                                        const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                                        T* __restrict__ gp, T* __restrict__ gq, int64_t E, int64_t K) {
+    constexpr bool PRECISE = sizeof(T) == 4;
+    const int64_t kv = K / VEC;
+    const int64_t items = E * kv;
+    for (int64_t chunk = blockIdx.x; chunk * 256 < items; chunk += gridDim.x) {   // a workgroup step = 256 consecutive pieces
+        const int64_t item = chunk * 256 + threadIdx.x;
+        if (item >= items) continue;
+        const int64_t e = item / kv;
+        const int64_t c = (item - e * kv) * VEC;
+        const int64_t i = dst[e], j = src[e];
+        float gv[VEC];
+        load_vec<T, VEC>(g + i * ldg + c, gv);
+        if constexpr (F == F_CGCONV) {
+            float pf[VEC], ps[VEC], qf[VEC], qs[VEC], wf[VEC], ws[VEC], of[VEC], os[VEC];
+            load_vec<T, VEC>(p + i * ldp + c, pf);
+            load_vec<T, VEC>(p + i * ldp + K + c, ps);
+            load_vec<T, VEC>(q + j * ldq + c, qf);
+            load_vec<T, VEC>(q + j * ldq + K + c, qs);
+            if constexpr (HAS_W) {
+                load_vec<T, VEC>(w + e * ldw + c, wf);
+                load_vec<T, VEC>(w + e * ldw + K + c, ws);
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float zf = pf[v] + qf[v], zs = ps[v] + qs[v];
+                if constexpr (HAS_W) { zf = zf + wf[v]; zs = zs + ws[v]; }
+                const float sg = sigmoid_f(zf), sp = softplus_f<PRECISE>(zs);
+                of[v] = gv[v] * sp * (sg * (1.f - sg));       // d/dz_f  sigmoid(z_f) softplus(z_s)
+                os[v] = gv[v] * sg * sigmoid_f(zs);            // d/dz_s: softplus' = sigmoid
+            }
+            store_vec<T, VEC>(gp + e * 2 * K + c, of);
+            store_vec<T, VEC>(gp + e * 2 * K + K + c, os);
+        } else {   // F_FILM: p = [beta | gamma], message relu(gamma * q + beta)
+            float be[VEC], ga[VEC], qv[VEC], ob[VEC], og[VEC], oq[VEC];
+            load_vec<T, VEC>(p + i * ldp + c, be);
+            load_vec<T, VEC>(p + i * ldp + K + c, ga);
+            load_vec<T, VEC>(q + j * ldq + c, qv);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float a = ga[v] * qv[v] + be[v];
+                const float gm = a > 0.f ? gv[v] : 0.f;
+                ob[v] = gm;
+                og[v] = gm * qv[v];
+                oq[v] = gm * ga[v];
+            }
+            store_vec<T, VEC>(gp + e * 2 * K + c, ob);
+            store_vec<T, VEC>(gp + e * 2 * K + K + c, og);
+            store_vec<T, VEC>(gq + e * K + c, oq);
+        }
+    }
+}
+
+template <typename T, int F, bool HAS_W>
+int launch_edge_grad(const void* p, int64_t ldp, const void* q, int64_t ldq, const void* w, int64_t ldw, const void* g, int64_t ldg,
+                     const int64_t* src, const int64_t* dst, void* gp, void* gq, int64_t E, int64_t K, int vec, hipStream_t stream) {
+    const int64_t items = E * (K / vec);
+    const int grid = gnnops_grid_cap(gnnops_cdiv(items, 256), 256 * 32);
+#define GNNOPS_EG(V)                                                                                                              \
+    hipLaunchKernelGGL((edge_grad_kernel<T, F, HAS_W, V>), dim3(grid), dim3(256), 0, stream, (const T*)p, ldp, (const T*)q, ldq, \
+                       (const T*)w, ldw, (const T*)g, ldg, src, dst, (T*)gp, (T*)gq, E, K)
+    if (vec == Elem<T>::VEC) GNNOPS_EG(Elem<T>::VEC);
+    else GNNOPS_EG(1);
+#undef GNNOPS_EG
+    return gnnops_check_launch("edge_grad");
+}
+
+template <typename T>
+int dispatch_edge_grad(int functor, const void* p, int64_t ldp, const void* q, int64_t ldq, const void* w, int64_t ldw, const void* g,
+                       int64_t ldg, const int64_t* src, const int64_t* dst, void* gp, void* gq, int64_t E, int64_t K, int vec,
+                       hipStream_t stream) {
+    if (functor == F_CGCONV)
+        return w ? launch_edge_grad<T, F_CGCONV, true>(p, ldp, q, ldq, w, ldw, g, ldg, src, dst, gp, gq, E, K, vec, stream)
+                 : launch_edge_grad<T, F_CGCONV, false>(p, ldp, q, ldq, w, ldw, g, ldg, src, dst, gp, gq, E, K, vec, stream);
+    return launch_edge_grad<T, F_FILM, false>(p, ldp, q, ldq, w, ldw, g, ldg, src, dst, gp, gq, E, K, vec, stream);
+}
+}  // namespace
+
+extern "C" int gnnops_edge_grad(int functor, const void* p, int64_t ldp, const void* q, int64_t ldq, const void* w, int64_t ldw,
+                                const void* g, int64_t ldg, const int64_t* src, const int64_t* dst, void* gp, void* gq, int64_t E,
+                                int64_t K, int dtype, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(functor == F_CGCONV || functor == F_FILM, GNNOPS_EUNSUPPORTED,
+                   "edge_grad: functor %d has no per-edge gradient kernel (copy / add: the output gradient itself)", functor);
+    GNNOPS_REQUIRE(E >= 0 && K >= 0, GNNOPS_EINVAL, "edge_grad: negative size");
+    if (E == 0 || K == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(p && q && g && src && dst && gp && (functor == F_CGCONV || gq), GNNOPS_EINVAL, "edge_grad: null pointer");
+    GNNOPS_REQUIRE(ldp >= 2 * K && ldq >= (functor == F_CGCONV ? 2 : 1) * K && ldg >= K && (!w || ldw >= 2 * K), GNNOPS_EINVAL,
+                   "edge_grad: a row pitch is shorter than the row");
+    int es, vec;
+    switch (dtype) {
+        case GNNOPS_F32: es = 4; vec = 4; break;
+        case GNNOPS_F16: case GNNOPS_BF16: es = 2; vec = 8; break;
+        default: gnnops_set_error("edge_grad: unknown dtype %d", dtype); return GNNOPS_EINVAL;
+    }
+    bool wide = K % vec == 0;   // 16-B pieces need every row start 16-B aligned: pointers, pitches and the K offset of a part
+    auto ok = [&](const void* ptr, int64_t ld) { return !ptr || ((uintptr_t)ptr % 16 == 0 && (ld * es) % 16 == 0); };
+    wide = wide && ok(p, ldp) && ok(q, ldq) && ok(w, ldw) && ok(g, ldg) && ok(gp, 2 * K) && ok(gq, K) && (K * es) % 16 == 0;
+    const int v = wide ? vec : 1;
+    hipStream_t stream = (hipStream_t)s;
+    switch (dtype) {
+        case GNNOPS_F32: return dispatch_edge_grad<float>(functor, p, ldp, q, ldq, w, ldw, g, ldg, src, dst, gp, gq, E, K, v, stream);
+        case GNNOPS_F16: return dispatch_edge_grad<__half>(functor, p, ldp, q, ldq, w, ldw, g, ldg, src, dst, gp, gq, E, K, v, stream);
+        default: return dispatch_edge_grad<__hip_bfloat16>(functor, p, ldp, q, ldq, w, ldw, g, ldg, src, dst, gp, gq, E, K, v, stream);
+    }
+}

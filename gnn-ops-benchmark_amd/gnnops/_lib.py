@@ -75,6 +75,7 @@ SIGNATURES = {
     "gnnops_edge_reduce_hub_workspace_bytes": (_sz, [_i64, _i64]),
     "gnnops_edge_reduce_hubs": (_ci, [_ci, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _ci, _vp,
                                       _ci, ctypes.c_float, ctypes.c_float, _ci, _vp, _sz, _vp]),
+    "gnnops_edge_grad": (_ci, [_ci, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _ci, _vp]),
     "gnnops_spline_basis": (_ci, [_vp, _vp, _vp, _i64, _ci, _ci, _vp, _vp, _ci, _vp]),
     "gnnops_spline_weighting": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
     "gnnops_spline_conv": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _vp]),

@@ -10,9 +10,13 @@ state_dict moves between the two; the forward is NOT MessagePassing.propagate. A
 because every Linear a message applies to cat([x_i, x_j, e]) splits into per-node products: z W = x_i W_i + x_j W_j + e W_e.
 The [E, .] tensors of propagate (x_i, x_j, z, the messages) never exist.
 
-Forward / inference only (the reference times forward under torch.no_grad(), benchmark_convs.py:53-59): the layers freeze
-their parameters (requires_grad False) when built; a call that would need a gradient raises. Training goes through
-gnnops.layers / gnnops.autograd.
+Training (the reference's OpProfiler.py:259-292 profiles a train loop): GINConv, SAGEConv, CGConv and FiLMConv are
+differentiable — the dense products through gnnops.autograd.addmm, the edge pass through `_EdgeReduce` below, whose backward
+is the forward's own machinery run the other way: the output gradient gathered along the TRANSPOSED plan (copy messages), or
+one streaming kernel that writes the per-edge gradient of the message (gnnops_edge_grad: cgconv / film) followed by two
+segment sums over the plans the forward already holds (by destination for the p side, by source for the q side). Packed
+weight operands are cached only while nothing requires grad. PNAConv (min / max / std aggregators with degree scalers)
+stays forward-only: its parameters are frozen when it is built and a call that would need a gradient raises.
 """
 import ctypes
 
@@ -38,15 +42,28 @@ def _rows(t, what, parts, K):
     return t, (t.stride(0) if t.size(0) > 1 else t.size(1))
 
 
-def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=("sum",), scalers=(), avg_deg=None, out=None):
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=("sum",), scalers=(), avg_deg=None, out=None,
+                flip=False):
     """out[i] = [scaler_s(deg_i) * AGGR_a_{(j -> i) in edge_index} f(p[i], q[j], w[e])  for s in scalers for a in aggr].
 
-    edge_index int64 [2, E] = (source j, destination i), PyG's flow="source_to_target". See include/gnnops.h
-    (gnnops_edge_reduce) for the functors. ``out`` may be a column block of a wider buffer (what the layer would cat into).
-    The destination plan (rowptr, perm) and the plan-ordered source ids are cached under the edge_index tensor."""
+    edge_index int64 [2, E] = (source j, destination i), PyG's flow="source_to_target" (``flip=True``: the transposed graph,
+    row 0 = destinations — what the backward of a copy message runs). See include/gnnops.h (gnnops_edge_reduce) for the
+    functors. ``out`` may be a column block of a wider buffer (what the layer would cat into). The destination plan
+    (rowptr, perm) and the plan-ordered source ids are cached under the edge_index tensor. Differentiable in q, p, w and
+    add for one sum / mean aggregator without scalers and ``out=None`` (copy / cgconv / film messages)."""
+    if _wants_grad(q, p, w, add):
+        if len(aggr) != 1 or aggr[0] not in ("sum", "add", "mean") or scalers or out is not None or flip or functor == "add":
+            raise NotImplementedError("gnnops.conv.edge_reduce: an operand requires grad, but only one sum / mean aggregator "
+                                      "without scalers of a copy / cgconv / film message has a backward (PNAConv is forward-only)")
+        return _EdgeReduce.apply(functor, "mean" if aggr[0] == "mean" else "sum", edge_index, num_dst, q, p, w, add)
     _require_gpu(q, edge_index, p, w, add, out)
-    ops._refuse_grad("edge_reduce", q, p, w, add)
     edge_index, src_rows, dst_rows = _coo_rows_cols(edge_index, "edge_reduce")
+    if flip:
+        src_rows, dst_rows = dst_rows, src_rows
     nq, np_, nw = _PARTS[functor]
     if q.dim() != 2 or q.size(1) % nq:
         raise RuntimeError(f"edge_reduce: q must be [rows, {nq} * K]")
@@ -75,11 +92,12 @@ def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=
         raise RuntimeError("edge_reduce: out has one row per destination")
     out, ldo = _rows(out, "out", 1, width)
     avg_log, avg_lin = (1.0, 1.0) if avg_deg is None else (float(avg_deg["log"]), float(avg_deg["lin"]))
-    plan = get_plan(dst_rows, num_dst, owner=edge_index, tag=1, companion=src_rows)   # small graphs: col comes with the plan
+    # plans are cached under the [2, E] tensor: tag 1 = plan of row 1 (destinations), tag 0 = plan of row 0 (the flipped graph)
+    plan = get_plan(dst_rows, num_dst, owner=edge_index, tag=0 if flip else 1, companion=src_rows)   # small graphs: col comes with the plan
     if plan.col is not None or E == 0:
         col = plan.col if E else src_rows
     else:
-        col, _ = _csr_arrays(plan, src_rows, None, owner=edge_index, tag=0)
+        col, _ = _csr_arrays(plan, src_rows, None, owner=edge_index, tag=1 if flip else 0)
     c_aggr = (ctypes.c_int * len(aggr_ids))(*aggr_ids)
     c_scal = (ctypes.c_int * max(len(scal_ids), 1))(*scal_ids)
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
@@ -93,6 +111,72 @@ def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=
                                        ptr(hub_ws), hub_bytes, _stream())
     check(rc, "edge_reduce")
     return out
+
+
+class _EdgeReduce(torch.autograd.Function):
+    """One sum / mean edge pass, differentiable in q [N_src, .], p [N_dst, .], w [E, .] and add [N_dst, K].
+
+    backward, with g = grad_out (for mean: divided by max(deg, 1) per destination):
+      copy    d q[j] = sum over the edges OUT of j of g[i]        = the same edge pass over the transposed graph
+      cgconv  gz[e] = g[i] * d message / d z (gnnops_edge_grad), z = p[i] + q[j] + w[e]:
+              d p = segment sum of gz by destination, d q = segment sum by source, d w = gz
+      film    gp[e], gq[e] from the same kernel; d p = sum of gp by destination, d q = sum of gq by source
+      d add = grad_out."""
+
+    @staticmethod
+    def forward(ctx, functor, aggr, edge_index, num_dst, q, p, w, add):
+        out = edge_reduce(functor, q, edge_index, num_dst, p=p, w=w, add=add, aggr=(aggr,))
+        ctx.functor, ctx.aggr, ctx.num_dst, ctx.n_src = functor, aggr, num_dst, q.size(0)
+        ctx.has = (p is not None, w is not None, add is not None)
+        ctx.save_for_backward(edge_index, q, *(t for t in (p, w) if t is not None))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        edge_index, q, *rest = ctx.saved_tensors
+        has_p, has_w, has_add = ctx.has
+        p = rest.pop(0) if has_p else None
+        w = rest.pop(0) if has_w else None
+        need_q, need_p, need_w, need_add = ctx.needs_input_grad[4:8]
+        g = grad_out.contiguous()
+        d_add = g if (has_add and need_add) else None
+        index, src_rows, dst_rows = _coo_rows_cols(edge_index, "edge_reduce")
+        E = index.size(1)
+        plan_dst = get_plan(dst_rows, ctx.num_dst, owner=edge_index, tag=1, companion=src_rows)
+        if ctx.aggr == "mean":
+            deg = (plan_dst.rowptr[1:] - plan_dst.rowptr[:-1]).clamp(min=1).to(g.dtype)
+            g = g / deg.unsqueeze(1)
+        d_q = d_p = d_w = None
+        K = g.size(1)
+        if ctx.functor == "copy":
+            if need_q:
+                d_q = edge_reduce("copy", g, edge_index, ctx.n_src, flip=True)
+            return None, None, None, None, d_q, None, None, d_add
+        if E == 0:
+            d_q = torch.zeros_like(q) if need_q else None
+            d_p = torch.zeros_like(p) if need_p else None
+            d_w = torch.zeros_like(w) if (has_w and need_w) else None
+            return None, None, None, None, d_q, d_p, d_w, d_add
+        q_, ldq = _rows(q, "q", _PARTS[ctx.functor][0], K)
+        p_, ldp = _rows(p, "p", 2, K)
+        w_, ldw = _rows(w, "w", 2, K) if has_w else (None, 0)
+        gp = torch.empty((E, 2 * K), dtype=g.dtype, device=g.device)
+        gq = torch.empty((E, K), dtype=g.dtype, device=g.device) if ctx.functor == "film" else None
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        with torch.cuda.device(g.device):
+            check(_lib.load().gnnops_edge_grad(FUNCTORS[ctx.functor], ptr(p_), ldp, ptr(q_), ldq, ptr(w_), ldw, g.data_ptr(), g.stride(0),
+                                               src_rows.data_ptr(), dst_rows.data_ptr(), gp.data_ptr(), ptr(gq), E, K,
+                                               _dtype_code(g, "edge_grad"), _stream()), "edge_grad")
+        if need_p:
+            d_p = ops.scatter(gp, plan_dst, 0, None, None, "sum")
+            if p.size(1) != 2 * K:       # p was a column block wider than its 2K parts (never the case for the layers here)
+                d_p = torch.nn.functional.pad(d_p, (0, p.size(1) - 2 * K))
+        if need_q:
+            plan_src = get_plan(src_rows, ctx.n_src, owner=edge_index, tag=0)
+            d_q = ops.scatter(gq if gq is not None else gp, plan_src, 0, None, None, "sum")
+        if has_w and need_w:
+            d_w = gp
+        return None, None, None, None, d_q, d_p, d_w, d_add
 
 
 # ---- dense side: every weight block a layer applies per node, as ONE operand of the MFMA product ------------------------
@@ -110,29 +194,38 @@ class _Packed:
         """params: the Parameters the blocks are cut from; blocks: [(weight or a column slice of it [out, in], bias or None)]."""
         # Module.to() / .half() swap a parameter's data without touching its version counter: the pointer and dtype are in the key
         # tensors created under torch.inference_mode() have no version counter: nothing derived from them is cached
+        if _wants_grad(*params):     # training: the packed operand is part of the graph (cat / t are differentiable) and never cached
+            return self._pack(blocks, stack)
         cacheable = all(ops._version_of(t) is not None for t in params if t is not None)
         key = tuple((id(t), t._version, t.data_ptr(), t.dtype) for t in params if t is not None) if cacheable else None
         if key is None or key != self.key:
             with torch.no_grad():
-                if stack:
-                    self.weight = torch.cat([wt.t() for wt, _ in blocks], dim=0).contiguous()
-                    biases = [b for _, b in blocks if b is not None]
-                    self.bias = sum(biases[1:], biases[0]).contiguous() if biases else None
-                else:
-                    self.weight = torch.cat([wt.t() for wt, _ in blocks], dim=1).contiguous()
-                    if any(b is not None for _, b in blocks):
-                        self.bias = torch.cat([b if b is not None else wt.new_zeros(wt.size(0)) for wt, b in blocks]).contiguous()
-                    else:
-                        self.bias = None
+                self.weight, self.bias = self._pack(blocks, stack)
             self.key = key
             self._alive = list(params)   # the key holds ids: keep the tensors they name alive so that no id is handed out again
         return self.weight, self.bias
 
+    @staticmethod
+    def _pack(blocks, stack):
+        if stack:
+            weight = torch.cat([wt.t() for wt, _ in blocks], dim=0).contiguous()
+            biases = [b for _, b in blocks if b is not None]
+            bias = sum(biases[1:], biases[0]).contiguous() if biases else None
+        else:
+            weight = torch.cat([wt.t() for wt, _ in blocks], dim=1).contiguous()
+            if any(b is not None for _, b in blocks):
+                bias = torch.cat([b if b is not None else wt.new_zeros(wt.size(0)) for wt, b in blocks]).contiguous()
+            else:
+                bias = None
+        return weight, bias
+
 
 def _dense(x, packed):
     """x [N, D_in] @ weight [D_in, W] (+ bias row) on the MFMA kernels (gemm.hip)."""
+    from . import autograd
+
     weight, bias = packed
-    return ops.addmm(bias, x, weight) if bias is not None else ops.matmul(x, weight)
+    return autograd.addmm(bias, x, weight) if bias is not None else autograd.matmul(x, weight)
 
 
 def _linear(x, lin, cache):
@@ -144,6 +237,8 @@ def _pair(x):
 
 
 class _Layer(torch.nn.Module):
+    """GIN / SAGE / CGConv / FiLM are trainable (module docstring); `_freeze` / `_forward_only` are what PNAConv uses."""
+
     def _freeze(self):
         self.requires_grad_(False)
 
@@ -151,7 +246,7 @@ class _Layer(torch.nn.Module):
         if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
                                         any(t is not None and t.requires_grad for t in tensors)):
             raise RuntimeError(f"gnnops.conv.{type(self).__name__} is forward-only: freeze its parameters / call it under "
-                               "torch.no_grad() (training: gnnops.layers, gnnops.autograd)")
+                               "torch.no_grad() (trainable: GINConv, SAGEConv, CGConv, FiLMConv)")
 
 
 class GINConv(_Layer):

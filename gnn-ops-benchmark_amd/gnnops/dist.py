@@ -144,6 +144,28 @@ class HipLocal:
 
         return own, send_ids, send_rows
 
+    def route_counts(self, state, lo, hi, n_own, recv_ids_local):
+        """float32 [hi - lo]: contributions per owned destination = this rank's own edges (their local ids are the keys the
+        windowed partition of `route_begin` left in the workspace) + the ids that arrived. What turns the sums of the ONE
+        exchange into means: the ids travel anyway, so the counts need no second exchange."""
+        import ctypes
+
+        from . import _lib
+        from .ops import check, scatter
+
+        src, index, ws = state
+        n_loc = hi - lo
+        parts = [recv_ids_local]
+        if ws is not None and n_own:
+            ko, vo, bo = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+            check(_lib.load().gnnops_bucket_layout(src.size(0), n_loc, ctypes.byref(ko), ctypes.byref(vo), ctypes.byref(bo)),
+                  "bucket_layout")
+            parts.append(ws[ko.value: ko.value + 4 * n_own].view(torch.int32).long())    # local ids of the own edges
+        ids = torch.cat(parts) if len(parts) > 1 else parts[0]
+        if ids.numel() == 0:
+            return torch.zeros(n_loc, dtype=torch.float32, device=src.device)
+        return scatter(torch.ones(ids.numel(), dtype=torch.float32, device=src.device), ids, 0, None, n_loc, "sum")
+
     # ---- compact form (any reduce; what min / max / mul and return_arg use) -----------------------------------
 
     def split(self, src, index, n_total, lo, hi, reduce, own_dense, want_arg=False):
@@ -340,16 +362,23 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
         raise ValueError("sharded_scatter: return_arg needs reduce='min' or 'max'")
     if return_arg and exchange == "dense":
         raise NotImplementedError("sharded_scatter: return_arg needs the sparse / compact exchange")
-    if reduce == "mean":
-        kw = dict(group=group, local_scatter=local_scatter, exchange=exchange, local=local)
-        sums = sharded_scatter(src_local, index_local, n_total, "sum", **kw)
-        ones = torch.ones((src_local.shape[0], 1), dtype=src_local.dtype, device=src_local.device)
-        cnt = sharded_scatter(ones, index_local, n_total, "sum", **kw)
-        res = sums / cnt.clamp_(min=1)
-        if out_slab is not None:
-            out_slab.copy_(res)
-            return out_slab
-        return res
+    want_mean = reduce == "mean"
+    if want_mean:
+        if local is None and exchange == "sparse":
+            local = HipLocal()
+        one_exchange = (exchange == "sparse" and hasattr(local, "route_counts") and local.route_ready(src_local, lo, hi))
+        if _all_agree(one_exchange, src_local.device, group):
+            reduce = "sum"      # the edge-list exchange below, plus counts from the ids that travel anyway
+        else:
+            kw = dict(group=group, local_scatter=local_scatter, exchange=exchange, local=local)
+            sums = sharded_scatter(src_local, index_local, n_total, "sum", **kw)
+            ones = torch.ones((src_local.shape[0], 1), dtype=src_local.dtype, device=src_local.device)
+            cnt = sharded_scatter(ones, index_local, n_total, "sum", **kw)
+            res = sums / cnt.clamp_(min=1)
+            if out_slab is not None:
+                out_slab.copy_(res)
+                return out_slab
+            return res
 
     if exchange in ("sparse", "compact"):
         if reduce not in _SPARSE_REDUCES:
@@ -374,7 +403,10 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
             send_splits, recv_splits = _read_counts(_counts_by_owner(send_ids, per, world), world, group)
         if send_splits[rank] != 0 and not edge_list:
             raise RuntimeError("sharded_scatter: own destinations must not enter the exchange")
+        if want_mean and not edge_list:
+            raise RuntimeError("sharded_scatter: ranks disagree on the exchange form of reduce='mean'")
         if edge_list:
+            n_own_edges = send_splits[rank]
             send_splits = list(send_splits)
             send_splits[rank] = 0          # the own edges stay here (recv_splits[rank] is the mirror of it)
             recv_splits = list(recv_splits)
@@ -393,6 +425,9 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
             w.wait()
         if is_sum:
             slab = local.accumulate(own_part, recv_rows, recv_ids - lo, reduce)
+            if want_mean:   # sums -> means: divide by the number of contributions (own edges + received ids), at least 1
+                cnt = local.route_counts(state, lo, hi, n_own_edges, recv_ids - lo)
+                slab.div_(cnt.clamp_(min=1).unsqueeze(1))
         else:
             own_ids, own_rows, own_args = own_part
             # contributions in RANK order (received from ranks below, own, received from ranks above): the first
@@ -436,6 +471,13 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
     if reduce in ("min", "max"):
         out_slab = torch.where(torch.isinf(out_slab), torch.zeros_like(out_slab), out_slab)
     return out_slab
+
+
+def _all_agree(flag, device, group):
+    """True when `flag` holds on EVERY rank (the two forms of a mean are different protocols: all ranks take the same)."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item())
 
 
 _side_stream = {}

@@ -318,7 +318,18 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
         N = out.size(dim)
         init = 1
         if reduce == "mean":
-            raise NotImplementedError("scatter: reduce='mean' with out= is not supported")
+            # torch_scatter.scatter_mean with out=: the sums are accumulated INTO out, then out is divided by the per-group
+            # count (clamped to 1) — out = (out + sum) / max(count, 1). The count is one more (row) scatter of ones.
+            scatter(src, index, dim, out, None, "sum")
+            if row_index is not None:
+                cnt = scatter(torch.ones(E, dtype=torch.float32, device=src.device), row_index, 0, None, N, "sum")
+                shape = [1] * out.dim()
+                shape[dim] = N
+                cnt = cnt.view(shape)
+            else:
+                cnt = scatter(torch.ones(src.shape, dtype=torch.float32, device=src.device), index, dim, None, N, "sum")
+            out.div_(cnt.clamp_(min=1))
+            return out
     else:
         init = 0
         if dim_size is not None:

@@ -401,6 +401,20 @@ int gnnops_edge_reduce_hubs(int functor, const void* q, int64_t ldq, const void*
                             const int* scalers, int n_scalers, float avg_deg_log, float avg_deg_lin, int dtype,
                             void* hub_workspace, size_t hub_workspace_bytes, gnnops_stream_t stream);
 
+/* Backward of the edge pass for sum / mean aggregation — what lets GINConv / SAGEConv / CGConv / FiLMConv of gnnops.conv sit
+ * in a training loop (graph_benchmark/profile/OpProfiler.py:259-292 profiles one). Per edge e = (j -> i), in EDGE order,
+ * the gradient of the message with respect to the rows it was made from, given g[i] = d loss / d out[i] (for mean: already
+ * divided by max(deg_i, 1)):
+ *   CGCONV  z_f = p_f[i] + q_f[j] (+ w_f[e]), z_s likewise:
+ *           gp[e] = [ g * softplus(z_s) * sig(z_f) (1 - sig(z_f)) | g * sig(z_f) * sig(z_s) ]   (2K; gq: pass NULL — d q and d w
+ *           are the same rows)        d p[i] = sum of gp over the edges into i, d q[j] = sum over the edges out of j, d w = gp
+ *   FILM    a = gamma[i] * q[j] + beta[i], m = [a > 0]:  gp[e] = [ g m | g m q[j] ]  (2K = d beta | d gamma),  gq[e] = g m gamma[i]  (K)
+ * COPY / ADD messages need no call (their per-edge gradient is g[i] itself). The two sums are gnnops_segment_reduce over the
+ * destination plan and over the plan of the source ids. ld* = row pitches in elements; gp [E, 2K], gq [E, K] dense. */
+int gnnops_edge_grad(int functor, const void* p, int64_t ldp, const void* q, int64_t ldq, const void* w, int64_t ldw,
+                     const void* g, int64_t ldg, const int64_t* src, const int64_t* dst, void* gp, void* gq, int64_t E,
+                     int64_t K, int dtype, gnnops_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The remaining ops of the reference's list (ops.txt:17-19, 29-41) - SURVEY.md 8(f) rank 4. Neither package is in the
  * reference tree (torch-spline-conv 1.2.1, torch-cluster 1.5.9: requirements.txt:214, :210) and the reference has no

@@ -59,6 +59,14 @@ class OracleLocal:
 
         return own, send_ids, send_rows
 
+    def route_counts(self, state, lo, hi, n_own, recv_ids_local):
+        src, index, _ = state
+        idx = index.numpy()
+        mine = idx[(idx >= lo) & (idx < hi)] - lo
+        assert len(mine) == n_own
+        cnt = np.bincount(mine, minlength=hi - lo) + np.bincount(recv_ids_local.numpy(), minlength=hi - lo)
+        return torch.from_numpy(cnt.astype(np.float32))
+
     # ---- compact form
     def split(self, src, index, n_total, lo, hi, reduce, own_dense, want_arg=False):
         from oracle import oracle
@@ -152,6 +160,23 @@ def run(rank, world, init_file, n_total, e_local, d, out_dir):
             res[r] = sharded_scatter(src, idx, n_total, r, local_scatter=oracle_local_scatter).numpy()
         for r in ("sum", "min", "max", "mean", "mul"):
             res["sparse_" + r] = sharded_scatter(src, idx, n_total, r, local=OracleLocal()).numpy()
+        # reduce="mean" rides on the ONE exchange of the sums (the ids that travel give the counts): as many all-to-alls as a sum
+        calls = {"n": 0}
+        real_a2a = dist.all_to_all_single
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return real_a2a(*a, **k)
+
+        dist.all_to_all_single = counting
+        try:
+            sharded_scatter(src, idx, n_total, "sum", local=OracleLocal())
+            n_sum, calls["n"] = calls["n"], 0
+            sharded_scatter(src, idx, n_total, "mean", local=OracleLocal())
+            n_mean = calls["n"]
+        finally:
+            dist.all_to_all_single = real_a2a
+        res["a2a_calls_sum_mean"] = np.array([n_sum, n_mean])
         res["compact_sum"] = sharded_scatter(src, idx, n_total, "sum", local=OracleLocal(), exchange="compact").numpy()
         for r in ("min", "max"):
             val, arg = sharded_scatter(src, idx, n_total, r, local=OracleLocal(), return_arg=True)

@@ -45,6 +45,8 @@ def test_sharded_scatter_two_ranks():
                 else:
                     np.testing.assert_allclose(got["sparse_" + r], exp[lo:hi], rtol=1e-5, atol=1e-5, err_msg=r)
             np.testing.assert_allclose(got["sparse_sum_out"], got["sparse_sum"], rtol=0, atol=0)
+            n_sum, n_mean = got["a2a_calls_sum_mean"]
+            assert n_sum == 3 and n_mean == n_sum, (n_sum, n_mean)      # counts, ids, rows — a mean adds no exchange
             assert (got["sparse_sum"][5 - lo] == 0).all() if lo <= 5 < hi else True
             exp = oracle.scatter(src, idx, dim=0, dim_size=n_total, reduce="sum")
             np.testing.assert_allclose(got["compact_sum"], exp[lo:hi], rtol=1e-5, atol=1e-5)

@@ -23,20 +23,26 @@ def _unsupported_cases():
     """name -> (route that must hand it to the stock kernel, thunk)."""
     g = torch.Generator().manual_seed(77)
     dev = "cuda"
-    a64, b64 = torch.rand(33, 17, generator=g, dtype=torch.float64).to(dev), torch.rand(17, 9, generator=g, dtype=torch.float64).to(dev)
+    # GEMM / SpMM libraries may split K or add with atomics: integer-valued operands make every partial sum exact, so the
+    # stock result is the same whatever order it was added in
+    a64, b64 = torch.randint(-4, 5, (33, 17), generator=g).double().to(dev), torch.randint(-4, 5, (17, 9), generator=g).double().to(dev)
     ai, bi = torch.randint(-5, 5, (33, 17), generator=g).to(dev), torch.randint(-5, 5, (17, 9), generator=g).to(dev)
-    a32, b32, c32 = torch.rand(64, 48, generator=g).to(dev), torch.rand(48, 40, generator=g).to(dev), torch.rand(64, 40, generator=g).to(dev)
+    a32, b32, c32 = (torch.randint(-4, 5, sh, generator=g).float().to(dev) for sh in ((64, 48), (48, 40), (64, 40)))
+    r32 = torch.rand(64, 48, generator=g).to(dev)
+    p3 = torch.rand(8, 6, 4, generator=g).to(dev).permute(2, 0, 1)
     wide = torch.zeros(50, 64, device=dev)
     idx_full = torch.randint(0, 50, (200, 32), generator=g).to(dev)
-    src32 = torch.rand(200, 32, generator=g).to(dev)
+    # the stock float scatter / index_add kernels add with atomics in arrival order: only exactly representable sums
+    # (small integers) are the same from run to run of the STOCK kernel itself, so those cases carry integer-valued floats
+    src32 = torch.randint(0, 8, (200, 32), generator=g).float().to(dev)
     deg_index = torch.randint(0, 300, (1, 5000), generator=g).to(dev)
     m64 = torch.randint(0, 1000, (300, 257), generator=g).to(dev)
-    base = torch.rand(300, 64, generator=g).to(dev)
+    base = torch.randint(0, 8, (300, 64), generator=g).float().to(dev)
     idx = torch.randint(0, 300, (450,), generator=g).to(dev)
-    source = torch.rand(450, 64, generator=g).to(dev)
+    source = torch.randint(0, 8, (450, 64), generator=g).float().to(dev)
     half = torch.rand(64, 48, generator=g).half().to(dev)
-    sp64 = torch.nn.functional.dropout(torch.rand(40, 30, generator=g, dtype=torch.float64), p=0.8).to(dev).to_sparse()
-    d64 = torch.rand(30, 8, generator=g, dtype=torch.float64).to(dev)
+    sp64 = (torch.randint(1, 5, (40, 30), generator=g) * (torch.rand(40, 30, generator=g) < 0.2)).double().to(dev).to_sparse()
+    d64 = torch.randint(-4, 5, (30, 8), generator=g).double().to(dev)
     unc = torch.sparse_coo_tensor(torch.randint(0, 20, (2, 300), generator=g).to(dev), torch.randint(0, 9, (300,), generator=g).to(dev), (20, 20))
 
     def noncontig_scatter():
@@ -57,7 +63,7 @@ def _unsupported_cases():
                                                                       torch.ones_like(deg_index))),
         "sort int64 matrix dim 1": ("sort", lambda: torch.sort(m64, dim=1)),
         "sort int64 matrix dim 0 stable": ("sort.stable", lambda: torch.sort(m64, dim=0, stable=True)),
-        "sort transposed view": ("sort", lambda: torch.sort(a32.t(), dim=1)),
+        "sort transposed view": ("sort", lambda: torch.sort(r32.t(), dim=1)),
         "index_add_ alpha=2": ("index_add_", lambda: base.clone().index_add_(0, idx, source, alpha=2)),
         "index_add float64": ("index_add", lambda: torch.index_add(base.double(), 0, idx, source.double())),
         "index_select non-contiguous": ("index_select", lambda: torch.index_select(base.t(), 1, idx)),
@@ -65,7 +71,7 @@ def _unsupported_cases():
         "scatter_ reduce multiply int": ("scatter_.reduce", lambda: torch.ones(3, 300, dtype=torch.int32, device=dev).scatter_(
             1, deg_index.expand(3, -1).contiguous(), torch.full((3, 5000), 2, dtype=torch.int32, device=dev), reduce="multiply")),
         "clone plain": ("clone", lambda: half.clone()),
-        "contiguous of a 3-D permute": ("clone", lambda: torch.rand(8, 6, 4, generator=g).to(dev).permute(2, 0, 1).contiguous()),
+        "contiguous of a 3-D permute": ("clone", lambda: p3.contiguous()),
         "sparse.mm float64": ("addmm@SparseCUDA", lambda: torch.sparse.mm(sp64, d64)),
         "coalesce integer values": ("_coalesce@SparseCUDA", lambda: unc.coalesce().to_dense()),
     }
@@ -75,19 +81,32 @@ def _flat(res):
     return list(res) if isinstance(res, (tuple, list)) else [res]
 
 
+def _outcome(f):
+    """What the call does: its tensors, or the exception type and text it raises (this ROCm build has no integer `mm`:
+    under install() the SAME error must come out, not a different one and not a result)."""
+    try:
+        return [t.clone() for t in _flat(f())]
+    except Exception as exc:  # noqa: BLE001 - whatever the stock kernel raises is the contract
+        return (type(exc), str(exc).splitlines()[0])
+
+
 def test_unsupported_operands_get_the_stock_kernel_bit_for_bit(gn):
     from gnnops import aten
 
     cases = _unsupported_cases()
-    want = {k: [t.clone() for t in _flat(f())] for k, (_, f) in cases.items()}
+    want = {k: _outcome(f) for k, (_, f) in cases.items()}
+    assert sum(isinstance(w, list) for w in want.values()) >= len(cases) - 2      # nearly all of them are real results
     gn.install()
     try:
         for name, (route, f) in cases.items():
             aten.reset_stats()
-            got = _flat(f())
+            got = _outcome(f)
             if route in aten.routed_ops:
                 assert aten.stats[route][1] >= 1 and aten.stats[route][0] == 0, (name, route, aten.stats[route])
-            assert len(got) == len(want[name]), name
+            if isinstance(want[name], tuple):
+                assert got == want[name], (name, got, want[name])
+                continue
+            assert isinstance(got, list) and len(got) == len(want[name]), (name, got)
             for g_, w_ in zip(got, want[name]):
                 assert g_.dtype == w_.dtype and g_.shape == w_.shape and torch.equal(g_, w_), name
     finally:
@@ -101,8 +120,10 @@ def test_errors_of_the_stock_kernels_come_through(gn):
             torch.mm(torch.rand(3, 4, device="cuda"), torch.rand(5, 6, device="cuda"))
         with pytest.raises((RuntimeError, IndexError)):
             torch.index_select(torch.rand(3, 4, device="cuda"), 5, torch.tensor([0], device="cuda"))
-        with pytest.raises(RuntimeError):
-            torch.zeros(3, 4, device="cuda").scatter_add_(0, torch.zeros(2, 4, dtype=torch.int32, device="cuda"), torch.ones(2, 4, device="cuda"))
+        with pytest.raises(RuntimeError):       # index of another rank than self
+            torch.zeros(3, 4, device="cuda").scatter_add_(0, torch.zeros(4, dtype=torch.int64, device="cuda"), torch.ones(2, 4, device="cuda"))
+        with pytest.raises(RuntimeError):       # self and src of different dtypes
+            torch.zeros(3, 4, device="cuda").scatter_add_(0, torch.zeros(2, 4, dtype=torch.int64, device="cuda"), torch.ones(2, 4, device="cuda").half())
     finally:
         gn.uninstall()
 
@@ -160,16 +181,29 @@ def _linear_train_step(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_a_two_layer_linear_train_step_is_unchanged_by_install(gn, dtype):
-    """forward + backward + SGD of nn.Linear layers (addmm / mm on transposed weight views, fp32 and fp64): the routes hand
-    every one of these to the stock kernels, so the installed run equals the un-installed one bit for bit."""
-    want = _linear_train_step(dtype)
+    """forward + backward + SGD of nn.Linear layers (OpProfiler.py:259-292 trains models built from them): addmm / mm on
+    transposed weight views and every fp64 product go to the stock kernels — the fp64 run equals the un-installed one bit for
+    bit; in fp32 the one product with contiguous operands (grad_out @ weight) runs on the HIP GEMM and the step matches
+    within fp32 rounding."""
+    from gnnops import aten
+
+    want, again = _linear_train_step(dtype), _linear_train_step(dtype)
+    reproducible = all(torch.equal(a, b) for a, b in zip(want, again))     # is the vendor GEMM itself run-to-run exact here?
     gn.install()
     try:
+        aten.reset_stats()
         got = _linear_train_step(dtype)
+        hip = sum(c[0] for c in aten.stats.values())
+        stock = aten.stats["addmm"][1] + aten.stats["mm"][1]
     finally:
         gn.uninstall()
+    assert stock >= 12, aten.stats                                         # 3 steps x (2 addmm forward + >= 2 mm backward)
+    assert hip == 0 or dtype == torch.float32, aten.stats                  # fp64 never reaches a HIP kernel
     for g_, w_ in zip(got, want):
-        assert torch.equal(g_, w_)
+        if reproducible and hip == 0:
+            assert torch.equal(g_, w_)                                     # nothing but stock kernels ran: bit for bit
+        else:   # fp32: `grad_out @ weight` has contiguous operands and runs on the exact-fp32 MFMA kernel (another summation order)
+            torch.testing.assert_close(g_, w_, rtol=2e-5, atol=1e-6)
 
 
 def _message_passing_train_step():

@@ -120,3 +120,52 @@ def test_index_select_full_size(data):
     finally:
         ops._PUSH_MIN_TABLE_BYTES = saved
     assert torch.equal(pull, push)
+
+
+def test_index_add_full_size_into_a_nonzero_out(data):
+    """Tensor.index_add_ (benchmark_native_index_add_.py:13-16) at config 2's size, cold (one-shot) and with a plan, starting
+    from a NON-zero `self`: sampled rows recomputed sequentially on the host from self's row (bit-exact), the column checksum
+    sum(result) == sum(self) + sum(source), rows nothing reaches keep self's bits, and cold == plan bit for bit."""
+    gnnops, src, idx, plan = data
+    g = torch.Generator(device=src.device).manual_seed(7)
+    base = torch.rand(N, D, generator=g, device=src.device)
+    acc = base.clone()
+    ret = gnnops.index_add_(acc, 0, idx, src)                      # cold: partition + bucketed reduce from `self`
+    assert ret is acc
+    a, b = acc.double().sum(0), base.double().sum(0) + src.double().sum(0)
+    assert float(((a - b).abs() / b.abs()).max()) < 1e-6
+    rows = [0, 2, 54321, N // 2 + 1, N - 1]
+    for n, (pos, vals) in _host_rows(src, idx, rows).items():
+        ref = base[n].cpu().numpy().copy()
+        for v in vals:
+            ref = ref + v
+        assert np.array_equal(acc[n].cpu().numpy(), ref), f"row {n}"
+    empty = (plan.rowptr[1:] == plan.rowptr[:-1]).nonzero().flatten()[:1000]
+    assert empty.numel() > 0 and torch.equal(acc[empty], base[empty])
+    acc2 = base.clone()
+    gnnops.index_add_(acc2, 0, plan, src)                          # the plan form (seg_rows_kernel from `self`)
+    assert torch.equal(acc2, acc)
+
+
+def test_scatter_max_full_size(data):
+    """torch_scatter.scatter_max (benchmark_scatter_max.py:15-18) at config 2's size, cold: sampled destinations exact,
+    arg = the FIRST source row of the destination holding the maximum, empty groups (0, E), every arg inside its own
+    destination, and max(src) == -min(-src) with identical args (negation is exact)."""
+    gnnops, src, idx, plan = data
+    out, arg = gnnops.scatter_max(src, idx, dim=0, dim_size=N)     # cold path
+    rows = [5, 778, N // 3 + 1, N - 3]
+    for n, (pos, vals) in _host_rows(src, idx, rows).items():
+        if len(pos) == 0:
+            assert (out[n] == 0).all() and (arg[n] == E).all()
+            continue
+        exp = vals.max(0)
+        assert np.array_equal(out[n].cpu().numpy(), exp)
+        assert np.array_equal(arg[n].cpu().numpy(), pos[(vals == exp).argmax(0)])
+    nonempty = (plan.rowptr[1:] > plan.rowptr[:-1])
+    assert bool((arg[nonempty] < E).all()) and bool((arg[~nonempty] == E).all()) and bool((out[~nonempty] == 0).all())
+    sample = torch.randint(0, N, (100_000,), device=idx.device)
+    sample = sample[nonempty[sample]]
+    assert bool((idx[arg[sample, 5]] == sample).all())
+    assert bool((src[arg[sample, 5], 5] == out[sample, 5]).all())
+    neg, narg = gnnops.scatter_min(-src, plan, dim=0)
+    assert torch.equal(narg, arg) and torch.equal(-neg, out)

@@ -190,6 +190,35 @@ def test_scatter_full_index(gnnops, oracle, shape, dim, N, dname):
             _close(to_np(res), exp, dname, E, f"{r} {shape} d{dim} {dname}")
 
 
+@pytest.mark.parametrize("layout", ["R", "F", "R3"])
+def test_scatter_mean_accepts_out(gnnops, oracle, layout):
+    """torch_scatter.scatter_mean(src, index, dim, out=out): the sums are accumulated INTO out and the total is divided by
+    max(count, 1) — out = (out + sum) / max(count, 1) (torch_scatter/scatter.py scatter_mean; upstream accepts `out` for every
+    reduce, benchmark_scatter_mean.py:15-18 passes none). fp32, vs the sequential oracle: layout R bit-exact, F within the
+    layout-F tolerance."""
+    g = torch.Generator().manual_seed(8)
+    if layout == "R":
+        src, idx, dim, base = torch.rand(700, 48, generator=g), torch.randint(0, 90, (700,), generator=g), 0, torch.rand(90, 48, generator=g)
+    elif layout == "R3":
+        src, idx, dim, base = torch.rand(4, 300, 16, generator=g), torch.randint(0, 40, (300,), generator=g), 1, torch.rand(4, 40, 16, generator=g)
+    else:
+        src, idx, dim, base = torch.rand(200, 64, generator=g), torch.randint(0, 64, (200, 64), generator=g), 1, torch.rand(200, 64, generator=g)
+    idx[idx == 3] = 4                                            # an empty group keeps out / 1
+    out = base.clone().cuda()
+    ret = gnnops.scatter_mean(src.cuda(), idx.cuda(), dim, out=out)
+    assert ret.data_ptr() == out.data_ptr()
+    exp = oracle.scatter(src.numpy(), idx.numpy(), dim, out=base.numpy(), reduce="mean")
+    if layout == "F":
+        _close(out.cpu().numpy(), exp, "f32", 16, "mean out= F")
+    else:
+        assert_bits_equal(out.cpu().numpy(), exp, "mean out= " + layout)
+    import torch_scatter
+
+    out2 = base.clone().cuda()
+    assert torch_scatter.scatter_mean(src.cuda(), idx.cuda(), dim, out2) is out2      # the shim, positional `out`
+    assert torch.equal(out2, out) or layout == "F"
+
+
 def test_scatter_out_and_inplace_forms(gnnops, oracle):
     g = torch.Generator().manual_seed(7)
     src = torch.rand(500, 32, generator=g)
@@ -552,7 +581,7 @@ def test_layout_f_narrowed_index_copies(gnnops, oracle, reduce, N, dname):
                 continue          # routed through transposes (fresh tensors every call): nothing to key a copy on
             assert hit is not None and hit[3] not in (None,), "the second call must have narrowed (or recorded why not)"
             if hit[3] != "unsupported":
-                assert hit[3][1] == (2 if N <= 65536 else 4)
+                assert hit[3][1] == (2 if N <= 65535 else 4)      # 0xFFFF marks ids outside [0, N): N = 65536 takes four bytes
         d_idx[1, 1] = 0                                   # in-place write: version bump -> the copy is stale and dropped
         idx[1, 1] = 0
         exp = oracle.scatter(to_np(src), idx.numpy(), dim=0, dim_size=N, reduce=reduce, dtype=dname)

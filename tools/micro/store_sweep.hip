@@ -156,6 +156,15 @@ int main(int argc, char** argv) {
         const float ms2 = time_ms(it, [&] { CK(hipMemsetAsync(dst, 0x11, (size_t)n16 * 16, 0)); });
         printf("hipMemsetAsync     %8.3f ms %6.2f TB/s\n", ms2, 1.0 * n16 * 16 / ms2 / 1e9);
     }
+    if (argc > 3 && !strcmp(argv[3], "pmc")) {   // a handful of forms, for a rocprofv3 --pmc pass (kernel names carry <PAT, U, ST, RD>)
+        one<P_GS, 4, ST_NT, 1>(src, dst, n16, 16, 1);
+        one<P_WG, 4, ST_NT, 1>(src, dst, n16, 16, 1);
+        one<P_GS, 8, ST_PLAIN, 0>(src, dst, n16, 16, 1);
+        one<P_WG, 8, ST_PLAIN, 0>(src, dst, n16, 16, 1);
+        one<P_GS, 4, ST_NT, 5>(src, dst, n16, 16, 1);
+        one<P_WG, 4, ST_NT, 5>(src, dst, n16, 16, 1);
+        return 0;
+    }
     shape<1>(src, dst, n16, it);
     shape<0>(src, dst, n16, it);
     shape<5>(src, dst, n16, it);
