@@ -5,6 +5,7 @@
 // All HBM-bound byte movers: 16-B lane accesses along the feature dimension, several rows in flight
 // per lane group to cover the dependent index -> row latency. No MFMA here by design.
 #include "common.h"
+#include <stdlib.h>
 #include "hub.h"
 #include <type_traits>
 
@@ -17,37 +18,41 @@ constexpr int ROWS_IN_FLIGHT = 4;
 template <bool NT_LD, bool NT_ST, int RIF>
 __global__ __launch_bounds__(256) void select_rows_kernel(const char* __restrict__ in, const int64_t* __restrict__ index,
                                                           char* __restrict__ out, int64_t B, int64_t N, int64_t E,
-                                                          int64_t rowbytes, int gshift, int chunks) {
+                                                          int64_t rowbytes, int gshift, int chunks, int blk_map) {
     const int G = 1 << gshift;
     const int gl = threadIdx.x & (G - 1);
     const int gi = threadIdx.x >> gshift, groups = 256 >> gshift;
     const int64_t items = B * (int64_t)chunks * E;
     // one matrix, one chunk, every lane of a group on a piece of the row: item = position in `index`
     const bool whole = B == 1 && chunks == 1 && (int64_t)G * 16 == rowbytes;
-    // A workgroup step covers groups * RIF CONSECUTIVE items: its RIF stores per lane are one contiguous run of output
-    // rows, issued back to back (tools/micro/store_sweep.hip: a 1 : 1 copy in that shape runs at 5.8-5.9 TB/s, grid-strided
-    // 16-B lanes at 5.0-5.5).
+    // blk_map: a workgroup step covers groups * RIF CONSECUTIVE items — its RIF stores per lane are one contiguous run of
+    // output rows, issued back to back; otherwise the items are grid-strided (a lane's RIF rows a whole grid apart).
+    // Which one a launch takes: gnnops_index_select below (measured, same box: tools/ab_store_map.py).
     const int64_t step_items = (int64_t)groups * RIF;
-    for (int64_t step = blockIdx.x; step * step_items < items; step += gridDim.x) {
-        const int64_t item0 = step * step_items + gi;
-        if (whole && (step + 1) * step_items <= items) {
+    const int64_t ngroups = ((int64_t)gridDim.x * 256) >> gshift;
+    const int64_t ustride = blk_map ? groups : ngroups;
+    const int64_t step = blk_map ? (int64_t)gridDim.x * step_items : ngroups * RIF;
+    const int64_t lead = blk_map ? gi : 0;                      // item0 - lead = first item of a workgroup step
+    for (int64_t item0 = blk_map ? (int64_t)blockIdx.x * step_items + gi : ((int64_t)blockIdx.x * 256 + threadIdx.x) >> gshift;
+         item0 - lead < items; item0 += step) {
+        if (whole && (blk_map ? item0 - lead + step_items <= items : item0 + (RIF - 1) * ustride < items)) {
             // full step, straight-line: RIF index entries, RIF row pieces, RIF stores — every load of a phase in flight
             // (guarded loads each get a vmcnt(0) from the compiler's wait insertion, and nullable pointers become flat loads)
             int64_t n[RIF];
 #pragma unroll
-            for (int u = 0; u < RIF; ++u) n[u] = index[item0 + u * groups];
+            for (int u = 0; u < RIF; ++u) n[u] = index[item0 + u * ustride];
             u32x4 v[RIF];
 #pragma unroll
             for (int u = 0; u < RIF; ++u) v[u] = load16<NT_LD>(in + n[u] * rowbytes + (int64_t)gl * 16);
 #pragma unroll
-            for (int u = 0; u < RIF; ++u) store16<NT_ST>(out + (item0 + u * groups) * rowbytes + (int64_t)gl * 16, v[u]);
+            for (int u = 0; u < RIF; ++u) store16<NT_ST>(out + (item0 + u * ustride) * rowbytes + (int64_t)gl * 16, v[u]);
             continue;
         }
         const char* sp[RIF];
         char* dp[RIF];
 #pragma unroll
         for (int u = 0; u < RIF; ++u) {
-            const int64_t item = item0 + u * groups;
+            const int64_t item = item0 + u * ustride;
             sp[u] = nullptr;
             dp[u] = nullptr;
             if (item < items) {
@@ -630,8 +635,10 @@ extern "C" int gnnops_index_select(const void* input, const int64_t* index, void
         // nontemporal on both sides, 4 rows in flight per lane group, 64 workgroups per CU of grid:
         // the fastest of the variants swept with tools/time_sel.py at config 2
         const int sgrid = gnnops_grid_cap(gnnops_cdiv(items, (256 >> g.gshift) * ROWS_IN_FLIGHT), 256 * 64);
+        const char* mapenv = getenv("GNNOPS_PULL_MAP");   // g: the grid-strided map of rounds 1-2 (A/B: tools/ab_store_map.py; contiguous is 1.1-1.3 % faster)
+        const int blk_map = !(mapenv && mapenv[0] == 'g');
         hipLaunchKernelGGL((select_rows_kernel<true, true, ROWS_IN_FLIGHT>), dim3(sgrid), dim3(256), 0, stream,
-                           (const char*)input, index, (char*)out, B, N, E, rowbytes, g.gshift, g.chunks);
+                           (const char*)input, index, (char*)out, B, N, E, rowbytes, g.gshift, g.chunks, blk_map);
     } else {
         // K == 1 with a batch of rows that fit 64 KiB of LDS: rows parked on chip, the index shared by TB rows
         if (K == 1 && B > 1 && N >= 512 && E >= 256 && (size_t)N * elem_bytes <= 64 * 1024 && E * 32 >= N * elem_bytes &&

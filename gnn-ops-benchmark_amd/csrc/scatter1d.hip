@@ -1,0 +1,239 @@
+// scatter1d.hip — torch_scatter.scatter_min / scatter_max of a LONG 1-D tensor (src [E], index [E], K = 1) when the
+// destinations do not fit on chip: the reference's ">= 95 % of an A100-40GB" shapes, data/scatter_min.csv:2 and
+// data/scatter_max.csv:32 — 1 472 353 280 fp32 elements, index uniform over as many destinations
+// (op_bm_scripts/benchmark_scatter_min.py:15-18, torch_scatter.scatter_min(src, idx, dim)).
+//
+// The plan path sorts (destination, position) pairs completely (four 8-bit passes at 31 bits) and then gathers
+// src[position] at random: 4 useful bytes of every 64-B line (35 ms + 42 ms at that shape). Here the VALUE travels with
+// its destination, and the sort stops at buckets of 32768 destinations — what one workgroup's LDS holds:
+//
+//   1. radix passes over the destination bits above the low 15 only (sort_engine; two passes at 31 bits), key =
+//      (destination << 32) | fp32 bits of the value, payload = source position; the first pass builds its keys straight
+//      from (index, src) (KeyDstVal): nothing is packed or copied beforehand;
+//   2. bounds1d_kernel: one binary search per bucket boundary;
+//   3. minmax1d_kernel: a workgroup (1024 threads, 128 KiB of LDS) takes a bucket —
+//        a. table[d] = min / max over the bucket's pairs of the ORDERED u32 image of the value (LDS atomics; -0.0 counts as
+//           +0.0, NaNs and the reduce's identity, +inf / -inf, never win: the conventions of scatter_elem.hip / segment.hip);
+//        b. out[d] = that value (0 for a group nothing reached), stored;
+//        c. the table becomes positions: every pair whose value EQUALS out[d] does an LDS atomic min of
+//           (position << 1 | sign bit) — the smallest position among the winners, and whether that winner was a -0.0;
+//        d. arg[d] = position (E for a group nothing reached); out[d] gets its sign back if the winner was -0.0.
+//      Compares are exact, so the result is bit-identical to the sequential loop of the oracle: smallest position on ties.
+//
+// HBM-bound, and no random access anywhere: per element ~100 B of streamed traffic (first pass 12 + 12 read, 12 written;
+// second 8 + 12 read, 12 written; reduce 12 + 12 read) + 12 B written per destination.
+#include "common.h"
+#include "sort_engine.h"
+
+namespace {
+
+constexpr int LOW = 15, BUCKET = 1 << LOW;     // destinations per bucket = LDS table entries (4 B each: 128 KiB)
+constexpr int RTHREADS = 1024;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int bits_of(int64_t v) {   // smallest b with (1 << b) > v
+    int b = 0;
+    while (b < 40 && ((int64_t)1 << b) <= v) ++b;
+    return b;
+}
+
+struct Layout1d {
+    size_t keys_a, keys_b, vals_a, vals_b, tile_hist, digit_total, bptr, desc, total;
+};
+
+inline Layout1d layout1d(int64_t E, int64_t N) {
+    Layout1d l{};
+    const size_t tiles = (size_t)gnnops_cdiv(E > 0 ? E : 1, sortengine::TILE);
+    const size_t NB = (size_t)gnnops_cdiv(N > 0 ? N : 1, BUCKET);
+    size_t o = 0;
+    l.keys_a = o; o += align_up((size_t)E * 8, 256);
+    l.keys_b = o; o += align_up((size_t)E * 8, 256);
+    l.vals_a = o; o += align_up((size_t)E * 4, 256);
+    l.vals_b = o; o += align_up((size_t)E * 4, 256);
+    l.tile_hist = o; o += align_up(256 * tiles * 4, 256);
+    l.digit_total = o; o += 256 * 4;
+    l.bptr = o; o += align_up((NB + 2) * 8, 256);
+    l.desc = o; o += 256;
+    l.total = o;
+    return l;
+}
+
+// the sentinel destination of ids outside [0, N): the first id past the last bucket (a bucket of its own, never reduced)
+inline int64_t sentinel_of(int64_t N) { return gnnops_cdiv(N, BUCKET) * BUCKET; }
+inline int passes_of(int64_t N) { return (bits_of(sentinel_of(N)) - LOW + 7) / 8; }
+
+template <typename T>
+__global__ void set_desc_kernel(sortengine::DstValSrc<T>* d, const int64_t* idx, const T* val, int64_t n_dst, uint32_t sentinel) {
+    d->idx = idx; d->val = val; d->n_dst = n_dst; d->sentinel = sentinel;
+}
+
+// bptr[b] = first position whose (key >> 32) >> LOW >= b; bptr[NB] = first position of the sentinel bucket.
+__global__ void bounds1d_kernel(const uint64_t* __restrict__ keys, int64_t E, int64_t NB, int64_t* __restrict__ bptr) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > NB) return;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(keys[mid] >> (32 + LOW)) < b) lo = mid + 1; else hi = mid;
+    }
+    bptr[b] = lo;
+}
+
+// order-preserving u32 image of a float, -0.0 folded onto +0.0
+__device__ inline uint32_t ordered_of(uint32_t u) {
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float float_of_ordered(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+template <typename T, bool IS_MIN>
+__global__ __launch_bounds__(RTHREADS) void minmax1d_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos,
+                                                          const int64_t* __restrict__ bptr, T* __restrict__ out,
+                                                          int64_t* __restrict__ arg_out, int64_t E, int64_t N, int64_t NB) {
+    extern __shared__ uint32_t tab[];   // BUCKET entries
+    const int tid = threadIdx.x;
+    constexpr uint32_t EMPTY = IS_MIN ? 0xffffffffu : 0u;
+    const uint32_t ident = IS_MIN ? 0x7f800000u : 0xff800000u;   // +inf / -inf: the reduce's identity never wins
+    constexpr int U = 4;
+    for (int64_t b = blockIdx.x; b < NB; b += gridDim.x) {
+        const int64_t beg = bptr[b], end = bptr[b + 1];
+        const int64_t d0 = b << LOW;
+        const int nd = (int)((N - d0 < BUCKET) ? (N - d0) : BUCKET);
+        for (int d = tid; d < BUCKET; d += RTHREADS) tab[d] = EMPTY;
+        __syncthreads();
+        // a. the winning VALUE per destination
+        for (int64_t i0 = beg + tid; i0 < end; i0 += (int64_t)RTHREADS * U) {
+            uint64_t k[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * RTHREADS;
+                k[u] = keys[i < end ? i : end - 1];          // clamped: every load of the step in flight together
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + (int64_t)u * RTHREADS >= end) continue;
+                const uint32_t bits = (uint32_t)k[u];
+                if ((bits & 0x7fffffffu) > 0x7f800000u || bits == ident) continue;   // NaN, or the identity
+                const uint32_t d = (uint32_t)(k[u] >> 32) & (BUCKET - 1);
+                if (IS_MIN) atomicMin(&tab[d], ordered_of(bits)); else atomicMax(&tab[d], ordered_of(bits));
+            }
+        }
+        __syncthreads();
+        // b. store the values; c. the table turns into positions
+        for (int d = tid; d < BUCKET; d += RTHREADS) {
+            const uint32_t o = tab[d];
+            if (d < nd) Elem<T>::store(out + d0 + d, o == EMPTY ? 0.f : float_of_ordered(o));
+        }
+        __syncthreads();   // (orders the stores above before the loads of out below: same workgroup)
+        for (int d = tid; d < BUCKET; d += RTHREADS) tab[d] = 0xffffffffu;
+        __syncthreads();
+        for (int64_t i0 = beg + tid; i0 < end; i0 += (int64_t)RTHREADS * U) {
+            uint64_t k[U];
+            uint32_t p[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * RTHREADS;
+                const int64_t ic = i < end ? i : end - 1;
+                k[u] = keys[ic];
+                p[u] = pos[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + (int64_t)u * RTHREADS >= end) continue;
+                const uint32_t bits = (uint32_t)k[u];
+                if ((bits & 0x7fffffffu) > 0x7f800000u || bits == ident) continue;
+                const uint32_t d = (uint32_t)(k[u] >> 32) & (BUCKET - 1);
+                // the value this workgroup just stored (never read before by this CU: no stale line; volatile all the same)
+                const float won = Elem<T>::load(const_cast<const T*>(reinterpret_cast<const volatile T*>(out + d0 + d)));
+                if (__uint_as_float(bits) == won) atomicMin(&tab[d], (p[u] << 1) | (bits >> 31));
+            }
+        }
+        __syncthreads();
+        // d. positions out; a winner that was -0.0 gives its sign back
+        for (int d = tid; d < nd; d += RTHREADS) {
+            const uint32_t w = tab[d];
+            arg_out[d0 + d] = (w == 0xffffffffu) ? E : (int64_t)(w >> 1);
+            if (w != 0xffffffffu && (w & 1u)) {
+                const float won = Elem<T>::load(const_cast<const T*>(reinterpret_cast<const volatile T*>(out + d0 + d)));
+                if (won == 0.f) Elem<T>::store(out + d0 + d, -0.f);
+            }
+        }
+        __syncthreads();   // the table is re-initialised for the next bucket
+    }
+}
+
+template <typename T>
+int run1d(const void* src, const int64_t* index, void* out, int64_t* arg_out, int64_t E, int64_t N, int reduce, void* workspace,
+          hipStream_t stream, int (*first_pass)(const sortengine::DstValSrc<T>*, uint64_t*, uint32_t*, int64_t, int, uint32_t*, uint32_t*,
+                                                int, hipStream_t)) {
+    const Layout1d l = layout1d(E, N);
+    char* w = (char*)workspace;
+    uint64_t* kbuf[2] = {(uint64_t*)(w + l.keys_a), (uint64_t*)(w + l.keys_b)};
+    uint32_t* vbuf[2] = {(uint32_t*)(w + l.vals_a), (uint32_t*)(w + l.vals_b)};
+    uint32_t* tile_hist = (uint32_t*)(w + l.tile_hist);
+    uint32_t* digit_total = (uint32_t*)(w + l.digit_total);
+    int64_t* bptr = (int64_t*)(w + l.bptr);
+    auto* desc = (sortengine::DstValSrc<T>*)(w + l.desc);
+    const int tiles = (int)gnnops_cdiv(E, sortengine::TILE);
+    const int passes = passes_of(N);
+    hipLaunchKernelGGL(set_desc_kernel<T>, dim3(1), dim3(1), 0, stream, desc, index, (const T*)src, N, (uint32_t)sentinel_of(N));
+    const uint64_t* kin = nullptr;
+    const uint32_t* vin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 32 + LOW + 8 * p;
+        const int rc = p == 0 ? first_pass(desc, kbuf[0], vbuf[0], E, shift, tile_hist, digit_total, tiles, stream)
+                              : sortengine::pass_u64(kin, vin, kbuf[p & 1], vbuf[p & 1], E, shift, tile_hist, digit_total, tiles, stream);
+        if (rc != GNNOPS_OK) return rc;
+        kin = kbuf[p & 1]; vin = vbuf[p & 1];
+    }
+    const int64_t NB = gnnops_cdiv(N, BUCKET);
+    hipLaunchKernelGGL(bounds1d_kernel, dim3((unsigned)gnnops_cdiv(NB + 1, 256)), dim3(256), 0, stream, kin, E, NB, bptr);
+    const int grid = (int)(NB < 256 ? NB : 256);
+    const size_t lds = (size_t)BUCKET * 4;
+    static bool configured[2] = {false, false};
+    const bool is_min = reduce == GNNOPS_MIN;
+    const void* fn = is_min ? reinterpret_cast<const void*>(&minmax1d_kernel<T, true>) : reinterpret_cast<const void*>(&minmax1d_kernel<T, false>);
+    if (!configured[is_min]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return gnnops_check_launch("scatter1d attribute");
+        configured[is_min] = true;
+    }
+    if (is_min)
+        hipLaunchKernelGGL((minmax1d_kernel<T, true>), dim3(grid), dim3(RTHREADS), lds, stream, kin, vin, bptr, (T*)out, arg_out, E, N, NB);
+    else
+        hipLaunchKernelGGL((minmax1d_kernel<T, false>), dim3(grid), dim3(RTHREADS), lds, stream, kin, vin, bptr, (T*)out, arg_out, E, N, NB);
+    return gnnops_check_launch("scatter1d_minmax");
+}
+
+}  // namespace
+
+extern "C" size_t gnnops_scatter1d_workspace_bytes(int64_t E, int64_t N) {
+    if (E < 0 || N < 0) return 0;
+    return layout1d(E, N).total;
+}
+
+// out[n] = min / max of src[e] over index[e] == n (0 where nothing arrives), arg_out[n] = smallest such e holding it (E where
+// nothing arrives). GNNOPS_EUNSUPPORTED — take gnnops_segment_reduce — unless the shape is the one this form is for:
+// BUCKET < N < 2^31 - BUCKET, 0 < E < 2^31.
+extern "C" int gnnops_scatter1d_minmax(const void* src, const int64_t* index, void* out, int64_t* arg_out, int64_t E, int64_t N,
+                                       int dtype, int reduce, void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(E >= 0 && N >= 0, GNNOPS_EINVAL, "scatter1d_minmax: negative size");
+    GNNOPS_REQUIRE(reduce == GNNOPS_MIN || reduce == GNNOPS_MAX, GNNOPS_EUNSUPPORTED, "scatter1d_minmax: reduce %d (min / max only)", reduce);
+    GNNOPS_REQUIRE(N > BUCKET && N < ((int64_t)1 << 31) - BUCKET && E > 0 && E < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED,
+                   "scatter1d_minmax: shape outside this form (E=%lld N=%lld)", (long long)E, (long long)N);
+    GNNOPS_REQUIRE(src && index && out && arg_out, GNNOPS_EINVAL, "scatter1d_minmax: null pointer");
+    const Layout1d l = layout1d(E, N);
+    GNNOPS_REQUIRE(workspace && workspace_bytes >= l.total && (uintptr_t)workspace % 256 == 0, GNNOPS_EWORKSPACE,
+                   "scatter1d_minmax: workspace %zu < %zu (or not 256-B aligned)", workspace_bytes, l.total);
+    hipStream_t stream = (hipStream_t)s;
+    switch (dtype) {
+        case GNNOPS_F32: return run1d<float>(src, index, out, arg_out, E, N, reduce, workspace, stream, sortengine::pass_first_dstval_f32);
+        case GNNOPS_F16: return run1d<__half>(src, index, out, arg_out, E, N, reduce, workspace, stream, sortengine::pass_first_dstval_f16);
+        case GNNOPS_BF16:
+            return run1d<__hip_bfloat16>(src, index, out, arg_out, E, N, reduce, workspace, stream, sortengine::pass_first_dstval_bf16);
+    }
+    gnnops_set_error("scatter1d_minmax: unknown dtype %d", dtype);
+    return GNNOPS_EINVAL;
+}

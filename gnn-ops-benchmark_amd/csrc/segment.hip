@@ -12,6 +12,7 @@
 // Algorithmic bytes per destination row: deg*K*s (src) + deg*8 (index) + K*s (out)
 // [+ K*8 arg_out]. Extra real traffic: rowptr 4 B/row and perm 4 B/edge instead of the 8-B index.
 #include "common.h"
+#include <stdlib.h>
 #include "hub.h"
 
 namespace {
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
                                                        const int32_t* __restrict__ perm, T* __restrict__ out,
                                                        int64_t* __restrict__ arg_out, int64_t B, int64_t E, int64_t K,
                                                        int64_t N, int gshift, int kchunks, int init_from_out,
-                                                       int is_mean, hub::Ws hw, int hub_on) {
+                                                       int is_mean, hub::Ws hw, int hub_on, int blk_map) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr bool IS_ARG = (R == GNNOPS_MIN || R == GNNOPS_MAX);
     const int G = 1 << gshift;
@@ -38,13 +39,15 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
     const int64_t items = B * (int64_t)kchunks * N;
     const int64_t nblocks = (items + SEG_BLOCK - 1) / SEG_BLOCK;
 
-    // A workgroup visits SEG_BLOCK CONSECUTIVE items (= consecutive output rows) at a time, its lane groups interleaved
-    // over them: what it stores is one contiguous run (128 KiB for 512-B rows), written front to back. Grid-striding the
-    // items instead (each workgroup round 4 KiB here, the next one a whole grid away) ran 2-4 % slower at config 2 and
-    // is the pattern that loses 10-25 % in a plain copy / fill (tools/micro/store_sweep.hip, seg_store.hip, round 3).
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x)
-    for (int64_t item = blk * SEG_BLOCK + gi, iend = (blk + 1) * SEG_BLOCK < items ? (blk + 1) * SEG_BLOCK : items; item < iend;
-         item += groups) {
+    // blk_map: a workgroup visits SEG_BLOCK CONSECUTIVE items (= consecutive output rows) at a time, its lane groups
+    // interleaved over them: what it stores is one contiguous run (128 KiB for 512-B rows), written front to back. The other
+    // map grid-strides the items (each workgroup round 4 KiB here, the next one a whole grid away) — the pattern that loses
+    // 10-25 % in a plain copy / fill (tools/micro/store_sweep.hip); which one a launch takes: launch_seg below.
+    const int64_t outer_n = blk_map ? nblocks : (int64_t)gridDim.x;   // grid-stride: every workgroup runs the outer loop once
+    for (int64_t ob = blockIdx.x; ob < outer_n; ob += gridDim.x) {
+    const int64_t iend = blk_map ? ((ob + 1) * SEG_BLOCK < items ? (ob + 1) * SEG_BLOCK : items) : items;
+    const int64_t istep = blk_map ? groups : ((int64_t)gridDim.x * 256) >> gshift;
+    for (int64_t item = blk_map ? ob * SEG_BLOCK + gi : ((int64_t)blockIdx.x * 256 + threadIdx.x) >> gshift; item < iend; item += istep) {
         const int64_t n = item % N;
         const int64_t bc = item / N;
         const int chunk = (int)(bc % kchunks);
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256) void seg_rows_kernel(const T* __restrict__ src
             }
         }
         store16<NT>(out + oidx, Elem<T>::pack(acc));
+    }
     }
 }
 
@@ -315,7 +319,11 @@ int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void
         const int G = 1 << gshift;
         const int kchunks = (int)gnnops_cdiv(vecs, G);
         const int64_t items = B * kchunks * N;
-        int grid = gnnops_grid_cap(gnnops_cdiv(items, SEG_BLOCK), 256 * 16);
+        // GNNOPS_SEG_MAP=gs: the grid-strided map of rounds 1-2 (A/B on one box: tools/ab_store_map.py)
+        const char* mapenv = getenv("GNNOPS_SEG_MAP");
+        const int blk_map = !(mapenv && mapenv[0] == 'g');
+        int grid = blk_map ? gnnops_grid_cap(gnnops_cdiv(items, SEG_BLOCK), 256 * 16)
+                           : gnnops_grid_cap(gnnops_cdiv(items, 256 >> gshift), 256 * 64);
         // hubs (hub.h) are set aside when the caller brought the workspace for them: plan form, one matrix
         constexpr bool IS_ARG_R = (R == GNNOPS_MIN || R == GNNOPS_MAX);
         const bool want_arg = IS_ARG_R;
@@ -330,7 +338,7 @@ int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void
             }
         }
         hipLaunchKernelGGL((seg_rows_kernel<T, R>), dim3(grid), dim3(256), 0, stream, (const T*)src, rowptr, perm,
-                           (T*)out, arg_out, B, E, K, N, gshift, kchunks, init_from_out, is_mean, hw, hub_on);
+                           (T*)out, arg_out, B, E, K, N, gshift, kchunks, init_from_out, is_mean, hw, hub_on, blk_map);
         if (hub_on)
             hub::launch_pass<T, R, false>((const T*)src, perm, nullptr, nullptr, (T*)out, arg_out, hw, E, K, gshift, kchunks,
                                           init_from_out, is_mean, stream);

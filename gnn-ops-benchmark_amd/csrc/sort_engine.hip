@@ -39,4 +39,20 @@ int pass_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_ou
                                          num_tiles, stream);
 }
 
+int pass_first_dstval_f32(const DstValSrc<float>* desc, uint64_t* keys_out, uint32_t* vals_out, int64_t n, int shift,
+                          uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream) {
+    return run_pass<KeyDstVal<float>, true, true>(desc, nullptr, keys_out, vals_out, n, shift, tile_hist, digit_total, num_tiles, stream);
+}
+
+int pass_first_dstval_f16(const DstValSrc<__half>* desc, uint64_t* keys_out, uint32_t* vals_out, int64_t n, int shift,
+                          uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream) {
+    return run_pass<KeyDstVal<__half>, true, true>(desc, nullptr, keys_out, vals_out, n, shift, tile_hist, digit_total, num_tiles, stream);
+}
+
+int pass_first_dstval_bf16(const DstValSrc<__hip_bfloat16>* desc, uint64_t* keys_out, uint32_t* vals_out, int64_t n, int shift,
+                           uint32_t* tile_hist, uint32_t* digit_total, int num_tiles, hipStream_t stream) {
+    return run_pass<KeyDstVal<__hip_bfloat16>, true, true>(desc, nullptr, keys_out, vals_out, n, shift, tile_hist, digit_total, num_tiles,
+                                                          stream);
+}
+
 }  // namespace sortengine

@@ -48,6 +48,18 @@ struct KeyU64 {
     __device__ static inline Carry load(const In* p, int64_t i) { return p[i]; }
     __device__ static inline uint32_t digit(Carry k, int shift) { return (uint32_t)(k >> shift) & 255u; }
 };
+// 1-D scatter with the value carried beside its destination (scatter1d.hip): the key is built from two arrays.
+template <typename T>
+struct KeyDstVal {
+    using In = DstValSrc<T>;
+    using Carry = uint64_t;
+    __device__ static inline Carry load(const In* p, int64_t i) {
+        const int64_t d = p->idx[i];
+        const uint32_t hi = ((uint64_t)d < (uint64_t)p->n_dst) ? (uint32_t)d : p->sentinel;
+        return ((uint64_t)hi << 32) | (uint64_t)__float_as_uint(Elem<T>::load(p->val + i));
+    }
+    __device__ static inline uint32_t digit(Carry k, int shift) { return (uint32_t)(k >> shift) & 255u; }
+};
 // torch.sort on fp32: order-preserving map float -> u32 (negatives flipped entirely, positives get the
 // sign bit); NaNs sort last like torch (any NaN maps to the top key).
 struct KeyF32 {

@@ -262,7 +262,6 @@ class GINConv(_Layer):
             self.register_buffer("eps", torch.tensor([float(eps)]))
         self._packed = _Packed()
         self._eps_key, self._eps_host = None, float(eps)
-        self._freeze()
 
     def _eps_value(self):
         """eps as a host number, read back from the device only when the tensor changed (a read-back per forward would
@@ -276,10 +275,12 @@ class GINConv(_Layer):
 
     def forward(self, x, edge_index, size=None):
         x_src, x_dst = _pair(x)
-        self._forward_only(x_src, x_dst)
         n_dst = x_dst.size(0) if size is None else size[1]
-        eps = self._eps_value()
-        root = x_dst if eps == 0.0 else x_dst * (1.0 + eps)
+        if _wants_grad(self.eps):       # train_eps: eps is part of the graph
+            root = x_dst * (1.0 + self.eps)
+        else:
+            eps = self._eps_value()
+            root = x_dst if eps == 0.0 else x_dst * (1.0 + eps)
         h = edge_reduce("copy", x_src.contiguous(), edge_index, n_dst, add=root.contiguous())
         return _linear(h, self.nn, self._packed) if isinstance(self.nn, torch.nn.Linear) else self.nn(h)
 
@@ -302,19 +303,20 @@ class SAGEConv(_Layer):
         self.lin_l = torch.nn.Linear(in_src, self.out_channels, bias=self._bias, **kw)
         if self.root_weight:
             self.lin_r = torch.nn.Linear(in_dst, self.out_channels, bias=False, **kw)
-        self._freeze()
 
     def forward(self, x, edge_index, size=None):
         x_src, x_dst = _pair(x)
         if self.lin_l is None:   # in_channels = -1: sized by the first input, like PyG's lazy Linear
             self._build(x_src.size(1), x_dst.size(1), like=x_src)
-        self._forward_only(x_src, x_dst)
         n_dst = x_dst.size(0) if size is None else size[1]
         d_src = x_src.size(1)
         if self.root_weight:
-            h = torch.empty((n_dst, d_src + x_dst.size(1)), dtype=x_src.dtype, device=x_src.device)
-            h[:, d_src:] = x_dst[:n_dst]
-            edge_reduce("copy", x_src.contiguous(), edge_index, n_dst, aggr=("mean",), out=h[:, :d_src])
+            if _wants_grad(x_src, x_dst):     # in a graph the mean is a tensor of its own (the out= form has no backward)
+                h = torch.cat([edge_reduce("copy", x_src.contiguous(), edge_index, n_dst, aggr=("mean",)), x_dst[:n_dst]], dim=1)
+            else:
+                h = torch.empty((n_dst, d_src + x_dst.size(1)), dtype=x_src.dtype, device=x_src.device)
+                h[:, d_src:] = x_dst[:n_dst]
+                edge_reduce("copy", x_src.contiguous(), edge_index, n_dst, aggr=("mean",), out=h[:, :d_src])
             packed = self._packed.get([self.lin_l.weight, self.lin_r.weight, self.lin_l.bias],
                                       [(self.lin_l.weight, self.lin_l.bias), (self.lin_r.weight, None)], stack=True)
         else:
@@ -336,11 +338,9 @@ class CGConv(_Layer):
         self.lin_s = torch.nn.Linear(sum(self._ch) + dim, self._ch[1], bias=bias)
         self.bn = torch.nn.BatchNorm1d(self._ch[1]) if batch_norm else None
         self._pk_both, self._pk_dst, self._pk_src, self._pk_edge = _Packed(), _Packed(), _Packed(), _Packed()
-        self._freeze()
 
     def forward(self, x, edge_index, edge_attr=None):
         x_src, x_dst = _pair(x)
-        self._forward_only(x_src, x_dst, edge_attr)
         c_src, c_dst = self._ch
         K = c_dst
         Wf, Ws, bf, bs = self.lin_f.weight, self.lin_s.weight, self.lin_f.bias, self.lin_s.bias
@@ -389,12 +389,10 @@ class FiLMConv(_Layer):
         self.lin_skip = torch.nn.Linear(in_channels, out_channels, bias=False)
         self.film_skip = torch.nn.Linear(in_channels, 2 * out_channels, bias=False)
         self._packed = _Packed()
-        self._freeze()
 
     def forward(self, x, edge_index, edge_type=None):
         if isinstance(x, (tuple, list)):
             raise NotImplementedError("gnnops.conv.FiLMConv: bipartite input")
-        self._forward_only(x)
         o, R = self.out_channels, self.num_relations
         blocks = [(self.film_skip.weight, None), (self.lin_skip.weight, None)]
         for r in range(R):

@@ -263,6 +263,7 @@ def index_max(index):
 # --------------------------------------------------------------------------------------------------
 # scatter family
 # --------------------------------------------------------------------------------------------------
+_SCATTER1D_MIN_N = 1 << 22     # 1-D min / max over at least this many destinations takes the carried-value form (scatter1d.hip)
 _LDS_STRIP_BYTES = 160 * 1024 - 512   # csrc/scatter_elem.hip LDS_BUDGET: what one workgroup's strip of destinations may take
 
 
@@ -362,6 +363,18 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
 
     if row_index is not None and not is_plan and (E >= 2 ** 31 or N >= 2 ** 31):
         row_index = None  # beyond the plan's int32 range: the element-wise kernel takes int64 sizes
+    if (want_arg and init == 0 and row_index is not None and not is_plan and B == 1 and K == 1 and _SCATTER1D_MIN_N <= N < 2 ** 31 - 32768
+            and 0 < E < 2 ** 31):
+        # a long 1-D min / max (the reference's 1.47e9-element shapes): the value travels with its destination through a PARTIAL
+        # sort and a workgroup finishes each bucket of 32768 destinations in LDS (scatter1d.hip) — no full sort, no random gather
+        ws_bytes = L.gnnops_scatter1d_workspace_bytes(E, N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
+        with torch.cuda.device(src.device):
+            rc = L.gnnops_scatter1d_minmax(src.data_ptr(), row_index.data_ptr(), out.data_ptr(), arg.data_ptr(), E, N, dt, rcode,
+                                           ws.data_ptr(), ws_bytes, _stream())
+        if rc != _lib.EUNSUPPORTED:
+            check(rc, "scatter1d_minmax")
+            return out, arg
     with torch.cuda.device(src.device):
         vec = 16 // src.element_size()
         rows_ok = K % vec == 0 and src.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0     # rows of whole 16-B lanes

@@ -184,6 +184,16 @@ int gnnops_scatter_elementwise_ix(const void* src, const void* index, int index_
  * id: bound <= 65535 for out_bytes 2, < 2^31 for 4), which the element kernels drop as they drop it in the int64 index. */
 int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_bytes, int64_t bound, gnnops_stream_t stream);
 
+/* torch_scatter.scatter_min / scatter_max of a LONG 1-D tensor (benchmark_scatter_min.py:15-18 at the reference's ">= 95 % of
+ * memory" shapes, data/scatter_min.csv:2: 1 472 353 280 fp32 elements): src [E], index [E] int64, out [N], arg_out [N] int64.
+ * The value travels with its destination through radix passes over the destination bits above the low 15, and a workgroup
+ * finishes each bucket of 32768 destinations in LDS (csrc/scatter1d.hip) — no complete sort, no random gather. Same result
+ * as gnnops_segment_reduce (out 0 / arg E where nothing arrives, smallest position on ties, NaNs and the reduce's identity
+ * never win). GNNOPS_EUNSUPPORTED unless 32768 < N < 2^31 - 32768 and 0 < E < 2^31 and reduce is MIN or MAX. */
+size_t gnnops_scatter1d_workspace_bytes(int64_t E, int64_t N);
+int gnnops_scatter1d_minmax(const void* src, const int64_t* index, void* out, int64_t* arg_out, int64_t E, int64_t N,
+                            int dtype, int reduce, void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * torch.index_select (benchmark_native_index_select.py:12-15; also the first half of
  * benchmark_fused_index_select_reduce.py:12-20).  input [B,N,K], index int64 [E] -> out [B,E,K],

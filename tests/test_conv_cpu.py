@@ -35,8 +35,8 @@ def test_layer_parameter_names_and_shapes_follow_pyg():
                            "post_nns.0.0.bias": (2048,), "lin.weight": (2048, 2048), "lin.bias": (2048,)}
     assert pna.avg_deg["lin"] == pytest.approx((3 * 1 + 5 * 2 + 2 * 3) / 10) and pna.avg_deg["log"] == pytest.approx(
         (3 * np.log(2) + 5 * np.log(3) + 2 * np.log(4)) / 10)
-    for m in (conv.CGConv(4), pna):
-        assert not any(p.requires_grad for p in m.parameters()), "the layers are forward-only: parameters are frozen"
+    assert not any(p.requires_grad for p in pna.parameters()), "PNAConv is forward-only: its parameters are frozen when it is built"
+    assert all(p.requires_grad for p in conv.CGConv(4).parameters()), "CGConv / GIN / SAGE / FiLM are trainable"
     with pytest.raises(NotImplementedError):
         conv.PNAConv(4, 8, ["mean"], ["identity"], torch.tensor([1, 1]), pre_layers=2)
 

@@ -189,8 +189,9 @@ def test_edge_reduce_refuses_bad_arguments(conv):
     with pytest.raises((RuntimeError, ValueError)):
         conv.edge_reduce("copy", x.cpu(), ei.cpu(), 10)                           # CPU tensors are refused, not emulated
     xg = x.clone().requires_grad_(True)
-    with pytest.raises(RuntimeError):
-        conv.edge_reduce("copy", xg, ei, 10)
+    with pytest.raises(NotImplementedError):                                          # a form without a backward refuses a gradient
+        conv.edge_reduce("copy", xg, ei, 10, aggr=("max",))
+    assert conv.edge_reduce("copy", xg, ei, 10).requires_grad                        # sum / mean of a copy message has one
 
 
 @pytest.mark.parametrize("E,N", [(1, 1), (40, 21), (1023, 7), (1024, 1024), (1025, 40000), (18744, 9134), (24576, 300), (24576, 40000)])
@@ -350,19 +351,26 @@ def test_pna_conv(conv, ora, dtype, cfg):
     _close(got, want, dtype, "PNA")
 
 
-def test_layers_are_forward_only_and_work_outside_no_grad(conv):
-    """groq_script.py:135-137 warms the model up OUTSIDE torch.no_grad(): the layers freeze their parameters, so that works;
-    asking for a gradient is refused, not silently dropped."""
+def test_pna_is_forward_only_and_the_others_join_the_graph(conv):
+    """groq_script.py:135-137 warms the model up OUTSIDE torch.no_grad(). GIN / SAGE / CGConv / FiLM are differentiable
+    (tests/test_conv_train_gpu.py): such a call returns a result attached to the graph. PNAConv (min / max / std with degree
+    scalers) is forward-only: its parameters are frozen when it is built, and asking it for a gradient is refused, not dropped."""
     layer = conv.CGConv(11, 0).half().cuda()
     x = torch.rand(29, 11, device="cuda").half()
     ei = torch.randint(0, 29, (2, 56), device="cuda")
-    out = layer(x, ei)                     # grad mode on, nothing requires grad
-    assert out.shape == (29, 11) and not out.requires_grad
-    layer.lin_f.weight.requires_grad_(True)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        layer(x, ei)
+    out = layer(x, ei)                     # grad mode on, parameters trainable
+    assert out.shape == (29, 11) and out.requires_grad
     with torch.no_grad():
-        layer(x, ei)
+        assert not layer(x, ei).requires_grad
+    pna = conv.PNAConv(4, 8, ["mean", "max"], ["identity"], torch.tensor([0, 3, 5, 2])).cuda()
+    assert not any(p.requires_grad for p in pna.parameters())
+    xp = torch.rand(29, 4, device="cuda")
+    assert not pna(xp, ei).requires_grad   # grad mode on, nothing requires grad
+    pna.lin.weight.requires_grad_(True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        pna(xp, ei)
+    with torch.no_grad():
+        pna(xp, ei)
 
 
 def test_layers_under_inference_mode(conv, ora):

