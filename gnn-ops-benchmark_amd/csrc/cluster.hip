@@ -191,6 +191,53 @@ __global__ void random_walk_kernel(const int64_t* __restrict__ rowptr, const int
     }
 }
 
+// ---- random_walk with node2vec's return / in-out bias (p, q): rejection sampling as the package does it. The first step is
+// uniform; afterwards a candidate x drawn uniformly from the neighbours of the current node v is accepted with probability
+// (1/p, 1, 1/q) / max(1/p, 1, 1/q) depending on whether it IS the previous node t, is a neighbour of t, or neither. The
+// neighbour test is a binary search in x's adjacency, which must be sorted (the host side sorts it). One draw pair per
+// (walker, step, attempt): counter-based, reproducible per seed. ATTEMPTS bounds the loop (every wave must finish): after
+// that many rejections the last candidate is taken — at p, q within [1/64, 64] the chance of getting there is < 1e-6.
+constexpr int N2V_ATTEMPTS = 1024;
+__device__ inline bool has_neighbour(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col, int64_t v, int64_t w) {
+    int64_t lo = rowptr[v], hi = rowptr[v + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t c = col[mid];
+        if (c == w) return true;
+        if (c < w) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+__global__ void random_walk_n2v_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col, const int64_t* __restrict__ start,
+                                       int64_t S, int L, float prob_t, float prob_nb, float prob_far, uint64_t seed,
+                                       int64_t* __restrict__ out) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < S; w += (int64_t)gridDim.x * blockDim.x) {
+        int64_t cur = start[w], prev = -1;
+        out[w * (L + 1)] = cur;
+        for (int l = 0; l < L; ++l) {
+            const int64_t beg = rowptr[cur], deg = rowptr[cur + 1] - beg;
+            int64_t next = cur;
+            if (deg > 0) {
+                const uint64_t ctr = seed ^ ((uint64_t)w * 0x100000001b3ull + (uint64_t)l);
+                if (l == 0 || deg == 1) {
+                    next = col[beg + (int64_t)(((uint64_t)mix32(ctr) * (uint64_t)deg) >> 32)];
+                } else {
+                    for (int a = 0; a < N2V_ATTEMPTS; ++a) {
+                        const uint64_t c2 = ctr + (uint64_t)(a + 1) * 0x9e3779b97f4a7c15ull;
+                        next = col[beg + (int64_t)(((uint64_t)mix32(c2) * (uint64_t)deg) >> 32)];
+                        const float r = (float)(mix32(c2 ^ 0xd6e8feb86659fd93ull) >> 8) * (1.f / 16777216.f);   // [0, 1)
+                        const float accept = next == prev ? prob_t : (has_neighbour(rowptr, col, next, prev) ? prob_nb : prob_far);
+                        if (r < accept) break;
+                    }
+                }
+            }
+            prev = cur;
+            cur = next;
+            out[w * (L + 1) + l + 1] = cur;
+        }
+    }
+}
+
 // ---- graclus_cluster: greedy pairing of every node with one unmatched neighbour (the heaviest edge when weights are given) ----
 // The package walks the nodes in a random order, sequentially. The parallel form is handshake matching: every unmatched node
 // proposes along its best still-available edge; an edge whose two ends propose to each other is matched. "Best" is a total
@@ -301,6 +348,18 @@ extern "C" int gnnops_random_walk(const int64_t* rowptr, const int64_t* col, con
     const int grid = gnnops_grid_cap(gnnops_cdiv(walkers, 256));
     hipLaunchKernelGGL(random_walk_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, rowptr, col, start, walkers, walk_length, seed, out);
     return gnnops_check_launch("random_walk");
+}
+
+extern "C" int gnnops_random_walk_node2vec(const int64_t* rowptr, const int64_t* col, const int64_t* start, int64_t walkers, int walk_length,
+                                           double p, double q, uint64_t seed, int64_t* out, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(walkers >= 0 && walk_length >= 0 && p > 0 && q > 0, GNNOPS_EINVAL, "random_walk_node2vec: bad argument");
+    if (walkers == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(rowptr && start && out && col, GNNOPS_EINVAL, "random_walk_node2vec: null pointer");
+    const double mx = fmax(fmax(1.0 / p, 1.0), 1.0 / q);
+    const int grid = gnnops_grid_cap(gnnops_cdiv(walkers, 256));
+    hipLaunchKernelGGL(random_walk_n2v_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, rowptr, col, start, walkers, walk_length,
+                       (float)(1.0 / p / mx), (float)(1.0 / mx), (float)(1.0 / q / mx), seed, out);
+    return gnnops_check_launch("random_walk_node2vec");
 }
 
 // `rounds` propose + match rounds over a CSR adjacency (int64 rowptr / col, weight in CSR order or NULL). cluster: int64 [N],

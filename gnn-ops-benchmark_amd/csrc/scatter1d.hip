@@ -88,6 +88,11 @@ __device__ inline float float_of_ordered(uint32_t o) {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+// HOLD keys per thread stay in REGISTERS between the value phase and the position phase (24 x 1024 = 24576 pairs — more spills: the 128 registers a lane of a 1024-thread workgroup has hold 48 for the keys — of the mean
+// 32768-pair bucket of the reference's shape, E = N; what a bucket holds beyond that is streamed in both phases), so a bucket's keys are read from HBM once; the
+// positions are read in the second phase only.
+constexpr int HOLD = 24;
+
 template <typename T, bool IS_MIN>
 __global__ __launch_bounds__(RTHREADS) void minmax1d_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos,
                                                           const int64_t* __restrict__ bptr, T* __restrict__ out,
@@ -97,28 +102,54 @@ __global__ __launch_bounds__(RTHREADS) void minmax1d_kernel(const uint64_t* __re
     constexpr uint32_t EMPTY = IS_MIN ? 0xffffffffu : 0u;
     const uint32_t ident = IS_MIN ? 0x7f800000u : 0xff800000u;   // +inf / -inf: the reduce's identity never wins
     constexpr int U = 4;
+    auto skip = [&](uint32_t bits) { return (bits & 0x7fffffffu) > 0x7f800000u || bits == ident; };   // NaN, or the identity
+    auto value_step = [&](uint64_t k) {
+        const uint32_t bits = (uint32_t)k;
+        if (skip(bits)) return;
+        const uint32_t d = (uint32_t)(k >> 32) & (BUCKET - 1);
+        if (IS_MIN) atomicMin(&tab[d], ordered_of(bits)); else atomicMax(&tab[d], ordered_of(bits));
+    };
     for (int64_t b = blockIdx.x; b < NB; b += gridDim.x) {
         const int64_t beg = bptr[b], end = bptr[b + 1];
         const int64_t d0 = b << LOW;
         const int nd = (int)((N - d0 < BUCKET) ? (N - d0) : BUCKET);
+        const T* outr = out + d0;   // this bucket's values, read back in phase c (stored by this workgroup in phase b)
+        auto position_step = [&](uint64_t k, uint32_t p) {
+            const uint32_t bits = (uint32_t)k;
+            if (skip(bits)) return;
+            const uint32_t d = (uint32_t)(k >> 32) & (BUCKET - 1);
+            const float won = Elem<T>::load(outr + d);
+            if (__uint_as_float(bits) == won) atomicMin(&tab[d], (p << 1) | (bits >> 31));
+        };
         for (int d = tid; d < BUCKET; d += RTHREADS) tab[d] = EMPTY;
+        // the keys this thread holds: loads unconditional on clamped positions, all in flight while the table is initialised.
+        // Positions RELATIVE to the bucket, 32-bit (E < 2^31): one uniform base + a 32-bit lane offset per load instead of 32
+        // address pairs (which, beside the 64 registers of the keys themselves, spilled)
+        const uint64_t* kb = keys + beg;
+        const uint32_t* pb = pos + beg;
+        const uint32_t cnt = (uint32_t)(end - beg);
+        const uint32_t lastr = cnt ? cnt - 1 : 0;   // an empty bucket reads one element (inside the workspace), uses none
+        uint64_t held[HOLD];
+#pragma unroll
+        for (int u = 0; u < HOLD; ++u) {
+            const uint32_t r = (uint32_t)tid + (uint32_t)u * RTHREADS;
+            held[u] = kb[r < cnt ? r : lastr];
+        }
         __syncthreads();
         // a. the winning VALUE per destination
-        for (int64_t i0 = beg + tid; i0 < end; i0 += (int64_t)RTHREADS * U) {
+#pragma unroll
+        for (int u = 0; u < HOLD; ++u)
+            if ((uint32_t)tid + (uint32_t)u * RTHREADS < cnt) value_step(held[u]);
+        for (uint32_t r0 = (uint32_t)HOLD * RTHREADS + tid; r0 < cnt; r0 += RTHREADS * U) {
             uint64_t k[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t i = i0 + (int64_t)u * RTHREADS;
-                k[u] = keys[i < end ? i : end - 1];          // clamped: every load of the step in flight together
+                const uint32_t r = r0 + u * RTHREADS;
+                k[u] = kb[r < cnt ? r : lastr];
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (i0 + (int64_t)u * RTHREADS >= end) continue;
-                const uint32_t bits = (uint32_t)k[u];
-                if ((bits & 0x7fffffffu) > 0x7f800000u || bits == ident) continue;   // NaN, or the identity
-                const uint32_t d = (uint32_t)(k[u] >> 32) & (BUCKET - 1);
-                if (IS_MIN) atomicMin(&tab[d], ordered_of(bits)); else atomicMax(&tab[d], ordered_of(bits));
-            }
+            for (int u = 0; u < U; ++u)
+                if (r0 + u * RTHREADS < cnt) value_step(k[u]);
         }
         __syncthreads();
         // b. store the values; c. the table turns into positions
@@ -126,39 +157,44 @@ __global__ __launch_bounds__(RTHREADS) void minmax1d_kernel(const uint64_t* __re
             const uint32_t o = tab[d];
             if (d < nd) Elem<T>::store(out + d0 + d, o == EMPTY ? 0.f : float_of_ordered(o));
         }
-        __syncthreads();   // (orders the stores above before the loads of out below: same workgroup)
+        __syncthreads();   // orders the stores above before this workgroup's loads of them below
         for (int d = tid; d < BUCKET; d += RTHREADS) tab[d] = 0xffffffffu;
         __syncthreads();
-        for (int64_t i0 = beg + tid; i0 < end; i0 += (int64_t)RTHREADS * U) {
+        {   // the held keys' positions, PC at a time (all HOLD of them beside the keys would not fit 128 registers)
+            constexpr int PC = 8;
+#pragma unroll
+            for (int u0 = 0; u0 < HOLD; u0 += PC) {
+                uint32_t hp[PC];
+#pragma unroll
+                for (int u = 0; u < PC; ++u) {
+                    const uint32_t r = (uint32_t)tid + (uint32_t)(u0 + u) * RTHREADS;
+                    hp[u] = pb[r < cnt ? r : lastr];
+                }
+#pragma unroll
+                for (int u = 0; u < PC; ++u)
+                    if ((uint32_t)tid + (uint32_t)(u0 + u) * RTHREADS < cnt) position_step(held[u0 + u], hp[u]);
+            }
+        }
+        for (uint32_t r0 = (uint32_t)HOLD * RTHREADS + tid; r0 < cnt; r0 += RTHREADS * U) {
             uint64_t k[U];
             uint32_t p[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t i = i0 + (int64_t)u * RTHREADS;
-                const int64_t ic = i < end ? i : end - 1;
-                k[u] = keys[ic];
-                p[u] = pos[ic];
+                const uint32_t r = r0 + u * RTHREADS;
+                const uint32_t rc = r < cnt ? r : lastr;
+                k[u] = kb[rc];
+                p[u] = pb[rc];
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (i0 + (int64_t)u * RTHREADS >= end) continue;
-                const uint32_t bits = (uint32_t)k[u];
-                if ((bits & 0x7fffffffu) > 0x7f800000u || bits == ident) continue;
-                const uint32_t d = (uint32_t)(k[u] >> 32) & (BUCKET - 1);
-                // the value this workgroup just stored (never read before by this CU: no stale line; volatile all the same)
-                const float won = Elem<T>::load(const_cast<const T*>(reinterpret_cast<const volatile T*>(out + d0 + d)));
-                if (__uint_as_float(bits) == won) atomicMin(&tab[d], (p[u] << 1) | (bits >> 31));
-            }
+            for (int u = 0; u < U; ++u)
+                if (r0 + u * RTHREADS < cnt) position_step(k[u], p[u]);
         }
         __syncthreads();
         // d. positions out; a winner that was -0.0 gives its sign back
         for (int d = tid; d < nd; d += RTHREADS) {
             const uint32_t w = tab[d];
             arg_out[d0 + d] = (w == 0xffffffffu) ? E : (int64_t)(w >> 1);
-            if (w != 0xffffffffu && (w & 1u)) {
-                const float won = Elem<T>::load(const_cast<const T*>(reinterpret_cast<const volatile T*>(out + d0 + d)));
-                if (won == 0.f) Elem<T>::store(out + d0 + d, -0.f);
-            }
+            if (w != 0xffffffffu && (w & 1u) && Elem<T>::load(outr + d) == 0.f) Elem<T>::store(out + d0 + d, -0.f);
         }
         __syncthreads();   // the table is re-initialised for the next bucket
     }

@@ -24,7 +24,8 @@ constexpr int HIST_THREADS = 256;
 constexpr int HIST_WAVES = HIST_THREADS / 64;
 
 // --- key adapters: how a stored key yields the current 8-bit digit and how it is carried ---
-struct KeyI64Low32 {  // first pass of the plan builder: int64 index -> u32 key
+struct KeyI64Low32 {
+    template <typename P> __device__ static inline P open(P p) { return p; }   // what load() reads from: the key array itself  // first pass of the plan builder: int64 index -> u32 key
     using In = int64_t;
     using Carry = uint32_t;
     // the WHOLE 8-byte element is loaded (the asm barrier keeps the compiler from narrowing the load to the low dword): a
@@ -37,12 +38,14 @@ struct KeyI64Low32 {  // first pass of the plan builder: int64 index -> u32 key
     __device__ static inline uint32_t digit(Carry k, int shift) { return (k >> shift) & 255u; }
 };
 struct KeyU32 {
+    template <typename P> __device__ static inline P open(P p) { return p; }   // what load() reads from: the key array itself
     using In = uint32_t;
     using Carry = uint32_t;
     __device__ static inline Carry load(const In* p, int64_t i) { return p[i]; }
     __device__ static inline uint32_t digit(Carry k, int shift) { return (k >> shift) & 255u; }
 };
 struct KeyU64 {
+    template <typename P> __device__ static inline P open(P p) { return p; }   // what load() reads from: the key array itself
     using In = uint64_t;
     using Carry = uint64_t;
     __device__ static inline Carry load(const In* p, int64_t i) { return p[i]; }
@@ -53,16 +56,44 @@ template <typename T>
 struct KeyDstVal {
     using In = DstValSrc<T>;
     using Carry = uint64_t;
-    __device__ static inline Carry load(const In* p, int64_t i) {
-        const int64_t d = p->idx[i];
-        const uint32_t hi = ((uint64_t)d < (uint64_t)p->n_dst) ? (uint32_t)d : p->sentinel;
-        return ((uint64_t)hi << 32) | (uint64_t)__float_as_uint(Elem<T>::load(p->val + i));
+    // The descriptor is read ONCE per kernel (open) into registers, and its two arrays are addressed as GLOBAL memory: a
+    // pointer loaded from memory has no address space, so loads through it are flat loads that wait on both counters, and a
+    // field read under the range test puts a scalar load and a wait inside every element's load — the first version of
+    // this pass ran its 32 loads per lane one after the other (16.5 ms against 10.2 for the second pass, same bytes).
+    struct Src {
+        const __attribute__((address_space(1))) int64_t* idx;
+        const __attribute__((address_space(1))) T* val;
+        uint64_t n_dst;
+        uint32_t sentinel;
+    };
+    __device__ static inline Src open(const In* p) {
+        Src s;
+        s.idx = (const __attribute__((address_space(1))) int64_t*)p->idx;
+        s.val = (const __attribute__((address_space(1))) T*)p->val;
+        s.n_dst = (uint64_t)p->n_dst;
+        s.sentinel = p->sentinel;
+        return s;
+    }
+    __device__ static inline Carry load(const Src& s, int64_t i) {
+        const uint64_t d = (uint64_t)s.idx[i];
+        float v;
+        if constexpr (sizeof(T) == 4) {
+            v = *reinterpret_cast<const __attribute__((address_space(1))) float*>(s.val + i);
+        } else {   // 16-bit storage: the two bytes travel as an integer (class types do not copy out of an address space), then widen
+            const uint16_t bits = *reinterpret_cast<const __attribute__((address_space(1))) uint16_t*>(s.val + i);
+            T raw;
+            __builtin_memcpy(&raw, &bits, 2);
+            v = Elem<T>::load(&raw);
+        }
+        const uint32_t hi = d < s.n_dst ? (uint32_t)d : s.sentinel;
+        return ((uint64_t)hi << 32) | (uint64_t)__float_as_uint(v);
     }
     __device__ static inline uint32_t digit(Carry k, int shift) { return (uint32_t)(k >> shift) & 255u; }
 };
 // torch.sort on fp32: order-preserving map float -> u32 (negatives flipped entirely, positives get the
 // sign bit); NaNs sort last like torch (any NaN maps to the top key).
 struct KeyF32 {
+    template <typename P> __device__ static inline P open(P p) { return p; }   // what load() reads from: the key array itself
     using In = float;
     using Carry = uint32_t;
     __device__ static inline Carry load(const In* p, int64_t i) {
@@ -75,7 +106,7 @@ struct KeyF32 {
 };
 
 template <typename KA>
-__global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const typename KA::In* __restrict__ keys, int64_t n,
+__global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const typename KA::In* __restrict__ keys_arg, int64_t n,
                                                             int shift, uint32_t* __restrict__ tile_hist,
                                                             int num_tiles) {
     __shared__ uint32_t h[HIST_WAVES][RADIX];
@@ -89,6 +120,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const typename KA::I
     // its loads before the first histogram update: a load under a per-lane condition is waited for inside the branch
     // (one group of loads in flight at a time — the first version ran at 3.8 TB/s for that reason).
     constexpr int GROUPS = TILE / (HIST_THREADS * 4);
+    const auto keys = KA::open(keys_arg);
     if (lim == TILE) {
         typename KA::Carry k[GROUPS][4];
 #pragma unroll
@@ -138,7 +170,7 @@ __global__ __launch_bounds__(HIST_THREADS) void scan_kernel(uint32_t* __restrict
 }
 
 template <typename KA, bool IMPLICIT_VALS, bool WRITE_KEYS>
-__global__ __launch_bounds__(THREADS, (sizeof(typename KA::Carry) == 4 ? 4 : 2)) void scatter_kernel(const typename KA::In* __restrict__ keys_in,
+__global__ __launch_bounds__(THREADS, (sizeof(typename KA::Carry) == 4 ? 4 : 2)) void scatter_kernel(const typename KA::In* __restrict__ keys_arg,
                                                           const uint32_t* __restrict__ vals_in,
                                                           typename KA::Carry* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out, int64_t n, int shift,
@@ -167,6 +199,7 @@ __global__ __launch_bounds__(THREADS, (sizeof(typename KA::Carry) == 4 ? 4 : 2))
 
     Carry key[ROUNDS];
     uint32_t val[ROUNDS];
+    const auto keys_in = KA::open(keys_arg);
     if (base + TILE <= n) {  // a full tile (uniform): unconditional loads, all in flight together
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {

@@ -86,6 +86,7 @@ SIGNATURES = {
     "gnnops_radius": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _ci, ctypes.c_double, _ci, _vp, _ci, _vp]),
     "gnnops_fps": (_ci, [_vp, _vp, _vp, _vp, _i64, _ci, _vp, _vp, _ci, _vp]),
     "gnnops_random_walk": (_ci, [_vp, _vp, _vp, _i64, _ci, ctypes.c_uint64, _vp, _vp]),
+    "gnnops_random_walk_node2vec": (_ci, [_vp, _vp, _vp, _i64, _ci, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, _vp, _vp]),
     "gnnops_graclus_rounds": (_ci, [_vp, _vp, _vp, _i64, ctypes.c_uint64, _ci, _vp, _vp, _vp, _ci, _ci, _vp]),
     "gnnops_segment_composite": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp]),
     "gnnops_segment_composite_hubs": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, ctypes.c_double, _vp, _sz, _vp]),

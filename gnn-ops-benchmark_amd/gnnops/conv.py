@@ -413,14 +413,15 @@ class PNAConv(_Layer):
     """Principal neighbourhood aggregation (torch_geometric PNAConv; benchmark_convs.py:197-206: in 1, out 2048,
     aggregators mean/min/max/std, scalers identity/amplification/attenuation, deg = in-degree histogram).
     message = pre_nn([x_i, x_j (, enc(e))]) with ONE pre-layer is p_i + q_j (+ w_e); the aggregators and scalers come out of
-    one edge pass, written next to x into the [N, (1 + A S) F] operand of the post layer."""
+    one edge pass, written next to x into the [N, (1 + A S) F] operand of the post layer. pre_layers > 1: the first layer is
+    still split per node, the rest of the MLP runs on per-edge rows (see forward); post_layers > 1: more node-row products."""
 
     def __init__(self, in_channels, out_channels, aggregators, scalers, deg, edge_dim=None, towers=1, pre_layers=1,
                  post_layers=1, divide_input=False):
         super().__init__()
-        if pre_layers != 1 or post_layers != 1:
-            raise NotImplementedError("gnnops.conv.PNAConv: pre_layers and post_layers must be 1 (a deeper pre-MLP is not "
-                                      "linear in [x_i, x_j], so it cannot leave the edge loop)")
+        if pre_layers < 1 or post_layers < 1:
+            raise ValueError("PNAConv: pre_layers and post_layers must be >= 1")
+        self.pre_layers, self.post_layers = pre_layers, post_layers
         if divide_input and in_channels % towers or out_channels % towers:
             raise ValueError("PNAConv: channels must divide by towers")
         self.in_channels, self.out_channels = in_channels, out_channels
@@ -436,9 +437,15 @@ class PNAConv(_Layer):
         F = self.F_in
         if edge_dim is not None:
             self.edge_encoder = torch.nn.Linear(edge_dim, F)
-        self.pre_nns = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear((3 if edge_dim else 2) * F, F)) for _ in range(towers)])
+        def mlp(first_in, width_out, layers):   # PyG's PNAConv: Linear, then (ReLU, Linear) per extra layer
+            mods = [torch.nn.Linear(first_in, width_out)]
+            for _ in range(layers - 1):
+                mods += [torch.nn.ReLU(), torch.nn.Linear(width_out, width_out)]
+            return torch.nn.Sequential(*mods)
+
+        self.pre_nns = torch.nn.ModuleList([mlp((3 if edge_dim else 2) * F, F, pre_layers) for _ in range(towers)])
         width = (len(self.aggregators) * len(self.scalers) + 1) * F
-        self.post_nns = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(width, self.F_out)) for _ in range(towers)])
+        self.post_nns = torch.nn.ModuleList([mlp(width, self.F_out, post_layers) for _ in range(towers)])
         self.lin = torch.nn.Linear(out_channels, out_channels)
         self._pk = {}
         self._freeze()
@@ -468,8 +475,24 @@ class PNAConv(_Layer):
             w = _dense(e, self._cache(f"edge{t}").get([Wp], [(Wp[:, 2 * F:], None)])) if e is not None else None
             h = torch.empty((n, (1 + A * S) * F), dtype=x.dtype, device=x.device)
             h[:, :F] = xin
-            edge_reduce("add", pq[:, F:], edge_index, n, p=pq[:, :F], w=w, aggr=self.aggregators, scalers=self.scalers,
-                        avg_deg=self.avg_deg, out=h[:, F:])
-            outs.append(_linear(h, post, self._cache(f"post{t}")))
+            if self.pre_layers == 1:
+                edge_reduce("add", pq[:, F:], edge_index, n, p=pq[:, :F], w=w, aggr=self.aggregators, scalers=self.scalers,
+                            avg_deg=self.avg_deg, out=h[:, F:])
+            else:
+                # a deeper pre-MLP is not linear in [x_i, x_j]: only its FIRST layer leaves the edge loop (the split product
+                # above); its output is materialised per edge, the remaining (ReLU, Linear) pairs run as [E, F] products, and
+                # the aggregators take the finished messages as "copy" rows of a graph whose sources are the edges themselves
+                src_rows, dst_rows = edge_index[0].contiguous(), edge_index[1].contiguous()
+                m = ops.index_select(pq[:, :F].contiguous(), 0, dst_rows) + ops.index_select(pq[:, F:].contiguous(), 0, src_rows)
+                if w is not None:
+                    m = m + w
+                for li in range(1, self.pre_layers):
+                    m = _linear(torch.relu_(m), self.pre_nns[t][2 * li], self._cache(f"pre{t}.{li}"))
+                per_edge = torch.stack([torch.arange(m.size(0), device=m.device), dst_rows])
+                edge_reduce("copy", m, per_edge, n, aggr=self.aggregators, scalers=self.scalers, avg_deg=self.avg_deg, out=h[:, F:])
+            o = _linear(h, post, self._cache(f"post{t}"))
+            for li in range(1, self.post_layers):
+                o = _linear(torch.relu_(o), self.post_nns[t][2 * li], self._cache(f"post{t}.{li}"))
+            outs.append(o)
         out = outs[0] if T == 1 else torch.cat(outs, dim=1)
         return _linear(out, self.lin, self._cache("lin"))

@@ -274,18 +274,27 @@ def nearest(x, y, batch_x=None, batch_y=None):
 
 def random_walk(row, col, start, walk_length, p=1.0, q=1.0, coalesced=True, num_nodes=None, seed=None):
     """torch_cluster.random_walk(row, col, start, walk_length, p=1, q=1, coalesced, num_nodes) (ops.txt:41): [len(start),
-    walk_length + 1] node ids; each step moves to a uniformly drawn neighbour (a node without neighbours stays). p = q = 1
-    only (the node2vec bias needs rejection sampling, not built). ``seed`` (extra): fixes the draws; default from torch's RNG."""
-    if p != 1.0 or q != 1.0:
-        raise NotImplementedError("gnnops.random_walk: p and q must be 1")
+    walk_length + 1] node ids; each step moves to a drawn neighbour (a node without neighbours stays): uniformly for
+    p = q = 1, with node2vec's return / in-out bias otherwise (rejection sampling as the package: a candidate is accepted with
+    probability (1/p, 1, 1/q) / max(...) when it is the previous node / a neighbour of it / neither). ``seed`` (extra): fixes
+    the draws; default from torch's RNG."""
     _require_gpu(row, col, start)
+    if p <= 0 or q <= 0:
+        raise ValueError("random_walk: p and q must be positive")
+    biased = p != 1.0 or q != 1.0
     if num_nodes is None:
         num_nodes = int(max(row.max(), col.max())) + 1 if row.numel() else int(start.max()) + 1
-    # CSR adjacency from the plan of `row` (stable: a row's neighbours keep the caller's order; `coalesced` only says whether
-    # the caller already sorted them, which a uniform draw does not care about)
+    # CSR adjacency from the plan of `row` (stable: a row's neighbours keep the caller's order — all a uniform draw needs). The
+    # biased walk tests "is x adjacent to t" by binary search, so there the entries are first ordered by (row, col).
     rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=row.device)
     if row.numel():
-        plan = ops.Plan(row.contiguous(), num_nodes, col.contiguous())
+        row, col = row.contiguous(), col.contiguous()
+        if biased:
+            from .sparse import sort as _sort
+
+            _, order = _sort(row * num_nodes + col, 0, stable=True)
+            row, col = ops.index_select(row, 0, order), ops.index_select(col, 0, order)
+        plan = ops.Plan(row, num_nodes, col)
         rowptr = plan.rowptr.to(torch.int64)
         col = plan.col if plan.col is not None else col[plan.perm[: row.numel()].long()]
     start = start.contiguous()
@@ -294,8 +303,12 @@ def random_walk(row, col, start, walk_length, p=1.0, q=1.0, coalesced=True, num_
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     colc = col.contiguous() if col.numel() else torch.zeros(1, dtype=torch.int64, device=row.device)
     with torch.cuda.device(row.device):
-        check(_lib.load().gnnops_random_walk(rowptr.data_ptr(), colc.data_ptr(), start.data_ptr(), start.numel(), int(walk_length), int(seed),
-                                             out.data_ptr(), _stream()), "random_walk")
+        if biased:
+            check(_lib.load().gnnops_random_walk_node2vec(rowptr.data_ptr(), colc.data_ptr(), start.data_ptr(), start.numel(), int(walk_length),
+                                                          float(p), float(q), int(seed), out.data_ptr(), _stream()), "random_walk_node2vec")
+        else:
+            check(_lib.load().gnnops_random_walk(rowptr.data_ptr(), colc.data_ptr(), start.data_ptr(), start.numel(), int(walk_length), int(seed),
+                                                 out.data_ptr(), _stream()), "random_walk")
     return out
 
 

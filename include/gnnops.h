@@ -467,6 +467,12 @@ int gnnops_fps(const void* x, const int64_t* ptr, const int64_t* out_ptr, const 
                float* dist_workspace, int64_t* out, int dtype, gnnops_stream_t stream);
 int gnnops_random_walk(const int64_t* rowptr, const int64_t* col, const int64_t* start, int64_t walkers, int walk_length,
                        uint64_t seed, int64_t* out, gnnops_stream_t stream);
+/* torch_cluster.random_walk with node2vec's bias (p: return, q: in-out; ops.txt:41): after a uniform first step, a candidate drawn
+ * uniformly from the current node's neighbours is accepted with probability (1/p, 1, 1/q) / max(1/p, 1, 1/q) when it is the
+ * previous node / a neighbour of the previous node / neither (rejection sampling, as the package). Every row of the CSR
+ * adjacency must be sorted ascending (the neighbour test is a binary search). */
+int gnnops_random_walk_node2vec(const int64_t* rowptr, const int64_t* col, const int64_t* start, int64_t walkers, int walk_length,
+                                double p, double q, uint64_t seed, int64_t* out, gnnops_stream_t stream);
 int gnnops_graclus_rounds(const int64_t* rowptr, const int64_t* col, const void* weight, int64_t N, uint64_t seed, int rounds,
                           int64_t* cluster, int64_t* proposal, int* d_active, int finish, int dtype, gnnops_stream_t stream);
 

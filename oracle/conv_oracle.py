@@ -99,9 +99,20 @@ def film_conv(x, edge_index, lins, films, lin_skip, film_skip, edge_type=None, a
     return out
 
 
+def _mlp(z, layers):
+    """PNAConv's pre / post networks: Linear, then (ReLU, Linear) per extra layer; `layers` = (W, b) or a list of them."""
+    if isinstance(layers, tuple):
+        layers = [layers]
+    z = _lin(z, *layers[0])
+    for W, b in layers[1:]:
+        z = _lin(np.maximum(z, 0.0), W, b)
+    return z
+
+
 def pna_conv(x, edge_index, pre, post, lin, aggregators, scalers, avg_deg, edge_attr=None, edge_encoder=None, towers=1,
              divide_input=False):
-    """pre / post: per tower (W, b) of the single pre / post layer; lin: (W, b); edge_encoder: (W, b) or None."""
+    """pre / post: per tower (W, b) of a single pre / post layer, or the list of (W, b) of a deeper one; lin: (W, b);
+    edge_encoder: (W, b) or None."""
     x = np.asarray(x, np.float64)
     src, dst = edge_index
     n = x.shape[0]
@@ -115,7 +126,7 @@ def pna_conv(x, edge_index, pre, post, lin, aggregators, scalers, avg_deg, edge_
     for t in range(towers):
         xi, xj = xt[dst, t], xt[src, t]
         h = np.concatenate([xi, xj] + ([e] if e is not None else []), axis=-1)
-        m = _lin(h, *pre[t])
+        m = _mlp(h, pre[t])
         aggs = []
         for a in aggregators:
             if a == "std":
@@ -140,5 +151,5 @@ def pna_conv(x, edge_index, pre, post, lin, aggregators, scalers, avg_deg, edge_
             else:
                 raise ValueError(s)
         out = np.concatenate([xt[:, t]] + scaled, axis=-1)
-        outs.append(_lin(out, *post[t]))
+        outs.append(_mlp(out, post[t]))
     return _lin(np.concatenate(outs, axis=1), *lin)

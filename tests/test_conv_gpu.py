@@ -351,6 +351,31 @@ def test_pna_conv(conv, ora, dtype, cfg):
     _close(got, want, dtype, "PNA")
 
 
+@pytest.mark.parametrize("pre,post,edge", [(2, 1, None), (1, 3, None), (3, 2, 3)])
+def test_pna_conv_deeper_pre_and_post_networks(conv, ora, pre, post, edge):
+    """torch_geometric PNAConv(pre_layers, post_layers): Linear then (ReLU, Linear) per extra layer (/root/reference
+    ops.txt lists the layer; benchmark_convs.py:197-206 uses one of each). A deeper pre-MLP is not linear in [x_i, x_j]: its
+    first layer is still split per node, the rest runs on per-edge rows — against the per-edge float64 restatement."""
+    torch.manual_seed(7)
+    g = torch.Generator().manual_seed(11)
+    n, e, T = 400, 3000, 2
+    ei = _graph(9, n, e)
+    deg_hist = torch.bincount(torch.bincount(ei[1], minlength=n))
+    aggr, scal = ["mean", "min", "max", "std"], ["identity", "amplification", "attenuation"]
+    layer = conv.PNAConv(8, 24, aggr, scal, deg_hist, edge_dim=edge, towers=T, pre_layers=pre, post_layers=post).cuda()
+    x = _rand(g, n, 8)
+    ea = _rand(g, e, edge) if edge else None
+    with torch.no_grad():
+        got = layer(x.cuda(), ei.cuda(), None if ea is None else ea.cuda())
+    P = _np_params(layer)
+    pres = [[(P[f"pre_nns.{t}.{2 * li}.weight"], P[f"pre_nns.{t}.{2 * li}.bias"]) for li in range(pre)] for t in range(T)]
+    posts = [[(P[f"post_nns.{t}.{2 * li}.weight"], P[f"post_nns.{t}.{2 * li}.bias"]) for li in range(post)] for t in range(T)]
+    want = ora.pna_conv(_f64(x), ei.numpy(), pres, posts, (P["lin.weight"], P["lin.bias"]), aggr, scal, layer.avg_deg,
+                        None if ea is None else _f64(ea), (P["edge_encoder.weight"], P["edge_encoder.bias"]) if edge else None, towers=T)
+    assert got.shape == (n, 24)
+    _close(got, want, torch.float32, f"PNA pre={pre} post={post}")
+
+
 def test_pna_is_forward_only_and_the_others_join_the_graph(conv):
     """groq_script.py:135-137 warms the model up OUTSIDE torch.no_grad(). GIN / SAGE / CGConv / FiLM are differentiable
     (tests/test_conv_train_gpu.py): such a call returns a result attached to the graph. PNAConv (min / max / std with degree

@@ -203,8 +203,39 @@ def test_random_walk_properties():
     one = random_walk(r2.cuda(), c2.cuda(), torch.zeros(40000, dtype=torch.int64).cuda(), 1, num_nodes=5, seed=1)[:, 1].cpu()
     freq = torch.bincount(one, minlength=5)[1:].float() / 40000
     assert bool(((freq - 0.25).abs() < 0.01).all()), freq
-    with pytest.raises(NotImplementedError):
-        random_walk(row.cuda(), col.cuda(), start.cuda(), 3, p=2.0)
+    with pytest.raises(ValueError):
+        random_walk(row.cuda(), col.cuda(), start.cuda(), 3, p=0.0)
+
+
+@pytest.mark.parametrize("p,q", [(4.0, 1.0), (0.25, 2.0), (1.0, 0.25), (2.0, 4.0)])
+def test_random_walk_node2vec_bias(p, q):
+    """torch_cluster.random_walk(p, q) (ops.txt:41; node2vec): second-order walk. From t = 0, via v = 1, the next node x is
+    drawn with weight 1/p if x == t, 1 if x is adjacent to t, 1/q otherwise. Small undirected graph where all three kinds
+    exist among v's neighbours; 60 000 walks; empirical frequencies of the third node against the exact distribution, and
+    every step along an edge. Random by nature in the package too: a property test, parity unpinned."""
+    from torch_cluster import random_walk
+
+    #   0 - 1, 0 - 2, 1 - 2, 1 - 3, 1 - 4, 2 - 4   (both directions). From 0 via 1: back to 0 (1/p), 2 (adjacent to 0: 1), 3 and 4 (1/q)
+    und = [(0, 1), (0, 2), (1, 2), (1, 3), (1, 4), (2, 4)]
+    row = torch.tensor([a for a, b in und] + [b for a, b in und])
+    col = torch.tensor([b for a, b in und] + [a for a, b in und])
+    perm = torch.randperm(row.numel(), generator=torch.Generator().manual_seed(3))      # the caller's order is arbitrary
+    row, col = row[perm], col[perm]
+    S = 60000
+    walks = random_walk(row.cuda(), col.cuda(), torch.zeros(S, dtype=torch.int64).cuda(), 2, p=p, q=q, num_nodes=5, seed=11).cpu()
+    adj = torch.zeros(5, 5, dtype=torch.bool)
+    adj[row, col] = True
+    assert bool(adj[walks[:, 0], walks[:, 1]].all()) and bool(adj[walks[:, 1], walks[:, 2]].all())
+    first = torch.bincount(walks[:, 1], minlength=5).float() / S                         # first step uniform over {1, 2}
+    assert abs(float(first[1]) - 0.5) < 0.01 and abs(float(first[2]) - 0.5) < 0.01
+    via1 = walks[walks[:, 1] == 1, 2]
+    w = {0: 1 / p, 2: 1.0, 3: 1 / q, 4: 1 / q}
+    z = sum(w.values())
+    freq = torch.bincount(via1, minlength=5).float() / via1.numel()
+    for x, wx in w.items():
+        assert abs(float(freq[x]) - wx / z) < 0.012, (x, float(freq[x]), wx / z)
+    assert float(freq[1]) == 0.0
+    assert torch.equal(walks, random_walk(row.cuda(), col.cuda(), torch.zeros(S, dtype=torch.int64).cuda(), 2, p=p, q=q, num_nodes=5, seed=11).cpu())
 
 
 @pytest.mark.parametrize("weighted", [False, True])
