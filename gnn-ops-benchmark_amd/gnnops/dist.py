@@ -25,7 +25,8 @@ with GLOBAL destination ids anywhere in [0, n_total)); destination rows are part
 ``exchange="compact"`` — the same exchange of per-DESTINATION partial rows: every rank first reduces its edges per distinct
   destination (plan + segment reduce) and sends compact (id, row) lists; what min / max / mul and `return_arg` use (a
   received row must be a finished partial result there), and what pays on graphs where a rank holds many edges to the same
-  remote destination. Two host read-backs (the number of distinct destinations, then the counts).
+  remote destination. One host read-back since round 3 (the per-owner counts of distinct destinations, taken from the
+  touched-row mask before any list is built; `nonzero_static` sizes the lists from the host numbers).
 
 ``exchange="dense"`` — local scatter into a partial [n_total, D] buffer, then ONE `reduce_scatter_tensor`.
   Bytes on the wire per rank = (G-1)/G x n_total x row whatever the cut; kept for comparison and for
@@ -179,6 +180,18 @@ class HipLocal:
         first and overlap the two. One plan over the global ids; its row pointer restricted to touched rows is itself a
         CSR row pointer over perm (untouched rows are empty), so compact reductions are plain segment reductions.
         """
+        world = max(1, n_total // (hi - lo))
+        state, counts, extra = self.split_counts(src, index, n_total, lo, hi, world, own_dense)
+        host = torch.cat([counts, extra]).tolist() if extra is not None else counts.tolist()     # direct callers: read here
+        n_lo = sum(host[: lo // (hi - lo)])
+        return self.split_finish(state, sum(host[:world]), n_lo, host[world] if extra is not None else 0, reduce, own_dense, want_arg)
+
+    def split_counts(self, src, index, n_total, lo, hi, world, own_dense):
+        """First half of `split`, nothing read back: the plan over the global ids and, per owner, HOW MANY distinct remote
+        destinations this rank touches — a device int64 [world] (``extra``: [1], the number of own destinations touched,
+        when the own part is compact too). The caller reads these back together with the counts every other rank sends it
+        (`_read_counts`): the ONE host synchronisation of the compact exchange; `split_finish` then sizes everything from
+        the host numbers (`nonzero_static`, slices instead of masks)."""
         from .ops import Plan, _require_gpu
 
         _require_gpu(src, index)
@@ -188,26 +201,34 @@ class HipLocal:
             raise NotImplementedError("sharded_scatter(exchange='compact'): E and n_total must be < 2^31")
         src = src.contiguous()
         index = index.contiguous()
+        plan = Plan(index, n_total)
+        touched = plan.rowptr[1:] != plan.rowptr[:-1]
+        own_mask = None if own_dense else touched[lo:hi].clone()
+        touched[lo:hi] = False
+        counts = touched.view(world, hi - lo).sum(1)
+        extra = None if own_dense else own_mask.sum().view(1)
+        return (src, plan, touched, own_mask, lo, hi, n_total), counts, extra
+
+    def split_finish(self, state, n_remote, n_lo, n_own, reduce, own_dense, want_arg=False):
+        """Second half of `split` (sizes known on the host: ``n_remote`` distinct remote destinations, ``n_lo`` of them below
+        the own range, ``n_own`` own destinations touched): returns ``(own, ids, rows, args)`` as `split` documents."""
+        src, plan, touched, own_mask, lo, hi, n_total = state
         E, D = src.shape
         dev = src.device
-        plan = Plan(index, n_total)
         rowptr, perm = plan.rowptr, plan.perm
 
         def seg(rp, n_rows, out, arg=None):
             self._seg(src, rp, perm, n_rows, out, reduce, arg)
 
-        touched = rowptr[1:] != rowptr[:-1]
-        own_touched = None if own_dense else touched[lo:hi].nonzero().squeeze(1)
-        touched[lo:hi] = False
-        ids = touched.nonzero().squeeze(1)                       # int64, ascending, remote only (sizes: a read-back)
+        ids = torch.nonzero_static(touched, size=n_remote).squeeze(1)      # int64, ascending, remote only; no read-back
+        own_touched = None if own_dense else torch.nonzero_static(own_mask, size=n_own).squeeze(1)
         # ids below the own range (owners 0 .. rank-1) and above it: two runs of the compact row pointer
-        below = ids < lo
-        ids_lo, ids_hi = ids[below], ids[~below]
-        n_lo, n_hi = ids_lo.numel(), ids_hi.numel()
+        ids_lo, ids_hi = ids[:n_lo], ids[n_lo:]
+        n_hi = n_remote - n_lo
         # compact rowptrs: untouched rows are empty, so consecutive touched rows are adjacent in perm
         crow = torch.cat([rowptr[ids_lo], rowptr[lo:lo + 1], rowptr[ids_hi], rowptr[n_total:n_total + 1]])
-        rows = torch.empty((ids.numel(), D), dtype=src.dtype, device=dev)
-        args = torch.empty((ids.numel(), D), dtype=torch.int64, device=dev) if want_arg else None
+        rows = torch.empty((n_remote, D), dtype=src.dtype, device=dev)
+        args = torch.empty((n_remote, D), dtype=torch.int64, device=dev) if want_arg else None
         seg(crow[: n_lo + 1], n_lo, rows[:n_lo], None if args is None else args[:n_lo])
         seg(crow[n_lo + 1:], n_hi, rows[n_lo:], None if args is None else args[n_lo:])
 
@@ -217,9 +238,9 @@ class HipLocal:
                 seg(rowptr[lo:hi + 1], hi - lo, slab)
                 return slab
             orow = torch.cat([rowptr[lo:hi][own_touched], rowptr[hi:hi + 1]])
-            orows = torch.empty((own_touched.numel(), D), dtype=src.dtype, device=dev)
-            oargs = torch.empty((own_touched.numel(), D), dtype=torch.int64, device=dev) if want_arg else None
-            seg(orow, own_touched.numel(), orows, oargs)
+            orows = torch.empty((n_own, D), dtype=src.dtype, device=dev)
+            oargs = torch.empty((n_own, D), dtype=torch.int64, device=dev) if want_arg else None
+            seg(orow, n_own, orows, oargs)
             return own_touched, orows, oargs
 
         return own, ids, rows, args
@@ -245,11 +266,14 @@ class HipLocal:
                                                hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream()),
                   "segment_reduce")
 
-    def spmm_split(self, row, col, value, mat, n_total, lo, hi):
+    def spmm_split(self, row, col, value, mat, n_total, lo, hi, counts_only=False):
         """Source-partitioned SpMM: this rank's nonzeros (global output row, LOCAL column into its slab `mat` [K_g, D],
         value or None) multiplied out per output row and split by ownership, like `split` with own_dense=True:
         returns (own, ids, rows). One plan over the rows; a row pointer restricted to touched rows is a CSR row pointer,
-        so both the own slab and the compact remote rows are plain gnnops_spmm launches over slices of it."""
+        so both the own slab and the compact remote rows are plain gnnops_spmm launches over slices of it.
+        ``counts_only``: nothing is read back here — returns (own, per-owner counts of distinct remote rows [device], finish),
+        and ``finish(n_remote, n_lo)`` builds (ids, rows) once the caller has the numbers on the host (`sharded_spmm`: the one
+        read-back it shares with the exchange of the counts)."""
         from . import _lib
         from .ops import Plan, _dtype_code, _require_gpu, _stream, check
 
@@ -279,20 +303,27 @@ class HipLocal:
 
         touched = rowptr[1:] != rowptr[:-1]
         touched[lo:hi] = False
-        ids = touched.nonzero().squeeze(1)                       # sizes the compact lists: a read-back
-        below = ids < lo
-        ids_lo, ids_hi = ids[below], ids[~below]
-        n_lo = ids_lo.numel()
-        crow = torch.cat([rowptr[ids_lo], rowptr[lo:lo + 1], rowptr[ids_hi], rowptr[n_total:n_total + 1]])
-        rows = torch.empty((ids.numel(), D), dtype=mat.dtype, device=dev)
-        mm(crow[: n_lo + 1], n_lo, rows[:n_lo])
-        mm(crow[n_lo + 1:], ids.numel() - n_lo, rows[n_lo:])
+        counts = touched.view(max(1, n_total // (hi - lo)), hi - lo).sum(1)    # distinct remote rows per owner: device int64
+
+        def finish(n_remote, n_lo):
+            """Second half, sizes known on the host (one read-back, shared with the exchange of the counts)."""
+            ids = torch.nonzero_static(touched, size=n_remote).squeeze(1)
+            ids_lo, ids_hi = ids[:n_lo], ids[n_lo:]
+            crow = torch.cat([rowptr[ids_lo], rowptr[lo:lo + 1], rowptr[ids_hi], rowptr[n_total:n_total + 1]])
+            rows = torch.empty((n_remote, D), dtype=mat.dtype, device=dev)
+            mm(crow[: n_lo + 1], n_lo, rows[:n_lo])
+            mm(crow[n_lo + 1:], n_remote - n_lo, rows[n_lo:])
+            return ids, rows
 
         def own(out=None):
             slab = out if out is not None else torch.empty((hi - lo, D), dtype=mat.dtype, device=dev)
             mm(rowptr[lo:hi + 1], hi - lo, slab)
             return slab
 
+        if counts_only:
+            return own, counts, finish
+        host = counts.tolist()
+        ids, rows = finish(sum(host), sum(host[: lo // (hi - lo)]))
         return own, ids, rows
 
     def accumulate(self, slab, rows, ids_local, reduce):
@@ -314,15 +345,21 @@ class HipLocal:
         return res[0] if isinstance(res, tuple) else res
 
 
-def _read_counts(send_counts, world, group):
+def _read_counts(send_counts, world, group, extra=None):
     """Swap the per-owner counts with every rank and read both vectors back in ONE device-to-host copy: returns
-    (send_splits, recv_splits) as lists. Runs on the CURRENT stream (callers put it on a side stream to keep the
-    device busy underneath)."""
-    both = torch.empty(2 * world, dtype=torch.int64, device=send_counts.device)
+    (send_splits, recv_splits) as lists — and, when ``extra`` (a small device int64 vector that needs no exchange) is
+    given, its values as a third list from the same copy. Runs on the CURRENT stream (callers put it on a side stream to
+    keep the device busy underneath)."""
+    n_extra = 0 if extra is None else extra.numel()
+    both = torch.empty(2 * world + n_extra, dtype=torch.int64, device=send_counts.device)
     both[:world] = send_counts
-    dist.all_to_all_single(both[world:], both[:world], group=group)
+    if n_extra:
+        both[2 * world:] = extra
+    dist.all_to_all_single(both[world:2 * world], both[:world], group=group)
     host = both.tolist()
-    return host[:world], host[world:]
+    if extra is None:
+        return host[:world], host[world:2 * world]
+    return host[:world], host[world:2 * world], host[2 * world:]
 
 
 def _swap(tensors, send_splits, recv_splits, group):
@@ -389,6 +426,7 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
         edge_list = (exchange == "sparse" and is_sum and hasattr(local, "route") and local.route_ready(src_local, lo, hi))
         direct = is_sum and out_slab is not None and out_slab.is_contiguous() and out_slab.dtype == src_local.dtype
         send_args = None
+        e_sizes_host = None
         if edge_list:
             # the owner counts go round on a side stream while the partition of step 2 is already queued behind them on the
             # main one: the host waits for the counts only, the device never idles
@@ -397,6 +435,25 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
             state = local.route_begin(src_local, index_local, lo, hi)
             send_splits, recv_splits = _side_stream_counts(counts, ready, world, group)
             own, send_ids, send_rows = local.route(state, n_total, lo, hi, send_splits, rank)
+        elif hasattr(local, "split_counts"):
+            # compact form, ONE host read-back: the per-owner counts of distinct remote destinations (and the number of own
+            # ones) come from the touched-row mask before any list exists; the lists are then sized from the host numbers
+            state, counts, extra = local.split_counts(src_local, index_local, n_total, lo, hi, world, is_sum)
+            parts = [] if extra is None else [extra]
+            if return_arg:   # every rank's edge count (positions travel as GLOBAL, rank-major positions): same read-back
+                e_dev = torch.empty(world, dtype=torch.int64, device=counts.device)
+                dist.all_gather_into_tensor(e_dev, torch.full((1,), src_local.shape[0], dtype=torch.int64, device=counts.device), group=group)
+                parts.append(e_dev)
+            if parts:
+                send_splits, recv_splits, host_extra = _read_counts(counts, world, group, torch.cat(parts) if len(parts) > 1 else parts[0])
+            else:
+                send_splits, recv_splits = _read_counts(counts, world, group)
+                host_extra = []
+            n_own = host_extra[0] if extra is not None else 0
+            if return_arg:
+                e_sizes_host = host_extra[-world:]
+            own, send_ids, send_rows, send_args = local.split_finish(state, sum(send_splits), sum(send_splits[:rank]), n_own, reduce,
+                                                                     is_sum, want_arg=return_arg)
         else:
             own, send_ids, send_rows, send_args = local.split(src_local, index_local, n_total, lo, hi, reduce, is_sum,
                                                               want_arg=return_arg)
@@ -413,11 +470,12 @@ def sharded_scatter(src_local, index_local, n_total, reduce="sum", group=None, l
             recv_splits[rank] = 0
         payload = [send_ids, send_rows]
         if return_arg:
-            e_sizes = torch.empty(world, dtype=torch.int64, device=src_local.device)
-            dist.all_gather_into_tensor(e_sizes, torch.tensor([src_local.shape[0]], dtype=torch.int64, device=src_local.device),
-                                        group=group)
-            e_sizes = e_sizes.tolist()
-            e_off, e_total = sum(e_sizes[:rank]), sum(e_sizes)
+            if e_sizes_host is None:      # a `local` without the two-phase protocol: its own exchange and read-back
+                e_sizes = torch.empty(world, dtype=torch.int64, device=src_local.device)
+                dist.all_gather_into_tensor(e_sizes, torch.full((1,), src_local.shape[0], dtype=torch.int64, device=src_local.device),
+                                            group=group)
+                e_sizes_host = e_sizes.tolist()
+            e_off, e_total = sum(e_sizes_host[:rank]), sum(e_sizes_host)
             payload.append(send_args + e_off)          # positions travel as GLOBAL (rank-major) positions
         (recv_ids, recv_rows, *recv_rest), works = _swap(payload, send_splits, recv_splits, group)
         own_part = own(out_slab) if direct else own()          # runs while the all-to-all is in flight
@@ -524,8 +582,15 @@ def sharded_spmm(index_local, value_local, n_total, matrix_local, group=None, ou
         local = HipLocal()
     if index_local.dim() != 2 or index_local.size(0) != 2:
         raise ValueError("sharded_spmm: index_local must be [2, nnz]")
-    own, ids, rows = local.spmm_split(index_local[0], index_local[1], value_local, matrix_local, n_total, lo, hi)
-    send_splits, recv_splits = _read_counts(_counts_by_owner(ids, hi - lo, world), world, group)
+    import inspect
+
+    if "counts_only" in inspect.signature(local.spmm_split).parameters:      # one host read-back for the whole call
+        own, counts, finish = local.spmm_split(index_local[0], index_local[1], value_local, matrix_local, n_total, lo, hi, counts_only=True)
+        send_splits, recv_splits = _read_counts(counts, world, group)
+        ids, rows = finish(sum(send_splits), sum(send_splits[:rank]))
+    else:
+        own, ids, rows = local.spmm_split(index_local[0], index_local[1], value_local, matrix_local, n_total, lo, hi)
+        send_splits, recv_splits = _read_counts(_counts_by_owner(ids, hi - lo, world), world, group)
     if send_splits[rank] != 0:
         raise RuntimeError("sharded_spmm: own rows must not enter the exchange")
     (recv_ids, recv_rows), works = _swap([ids, rows], send_splits, recv_splits, group)

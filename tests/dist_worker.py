@@ -67,6 +67,22 @@ class OracleLocal:
         cnt = np.bincount(mine, minlength=hi - lo) + np.bincount(recv_ids_local.numpy(), minlength=hi - lo)
         return torch.from_numpy(cnt.astype(np.float32))
 
+    # ---- compact form, two-phase (the one-read-back protocol of HipLocal.split_counts / split_finish)
+    def split_counts(self, src, index, n_total, lo, hi, world, own_dense):
+        uniq = np.unique(index.numpy())
+        remote = uniq[(uniq < lo) | (uniq >= hi)]
+        counts = torch.from_numpy(np.bincount(remote // (hi - lo), minlength=world).astype(np.int64))
+        extra = None if own_dense else torch.tensor([int(((uniq >= lo) & (uniq < hi)).sum())])
+        return (src, index, n_total, lo, hi), counts, extra
+
+    def split_finish(self, state, n_remote, n_lo, n_own, reduce, own_dense, want_arg=False):
+        src, index, n_total, lo, hi = state
+        own, ids, rows, args = self.split(src, index, n_total, lo, hi, reduce, own_dense, want_arg)
+        assert ids.numel() == n_remote and int((ids < lo).sum()) == n_lo
+        if not own_dense:
+            assert own()[0].numel() == n_own
+        return own, ids, rows, args
+
     # ---- compact form
     def split(self, src, index, n_total, lo, hi, reduce, own_dense, want_arg=False):
         from oracle import oracle

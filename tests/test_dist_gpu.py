@@ -174,6 +174,23 @@ def test_sharded_scatter_single_rank_rccl(oracle):
             dense = sharded_scatter(src.cuda(), idx.cuda(), 400, "sum", exchange="dense").cpu().numpy()
             np.testing.assert_allclose(dense, oracle.scatter(src.numpy(), idx.numpy(), dim=0, dim_size=400, reduce="sum"),
                                        rtol=1e-6, atol=1e-6)
+            # host read-backs per step: the compact exchange (min / max / mul, return_arg) reads back ONCE —
+            # the per-owner counts — and sizes its lists from the host numbers; counted with PyTorch's sync debug mode
+            import warnings
+
+            d_src, d_idx = src.cuda(), idx.cuda()
+            for kwargs in (dict(reduce="max"), dict(reduce="min", return_arg=True), dict(reduce="sum", exchange="compact")):
+                sharded_scatter(d_src, d_idx, 400, **kwargs)              # warm: allocator, lazy initialisation
+                torch.cuda.synchronize()
+                torch.cuda.set_sync_debug_mode("warn")
+                try:
+                    with warnings.catch_warnings(record=True) as seen:
+                        warnings.simplefilter("always")
+                        sharded_scatter(d_src, d_idx, 400, **kwargs)
+                finally:
+                    torch.cuda.set_sync_debug_mode("default")
+                syncs = [w for w in seen if "synchroniz" in str(w.message).lower()]
+                assert len(syncs) <= 1, (kwargs, [str(w.message)[:120] for w in syncs])
         finally:
             dist.destroy_process_group()
 
