@@ -20,6 +20,12 @@
 //        d. arg[d] = position (E for a group nothing reached); out[d] gets its sign back if the winner was -0.0.
 //      Compares are exact, so the result is bit-identical to the sequential loop of the oracle: smallest position on ties.
 //
+// Sums / means / products (gnnops_scatter1d_sum) keep the sequential order of the oracle — LDS float atomics would not —
+// so there the sort goes one pass further, to buckets of 256 destinations (bits 8 and up: three passes at 31 bits), and a
+// 256-thread workgroup finishes a bucket as bucket.hip does for rows: a stable counting sort of its (destination & 255, value)
+// pairs in LDS (ballot ranking, chunks of 4096 in source order), then thread d adds destination d's values one after the
+// other, in source position order: bit-identical to the sequential loop. No position travels (means count their lists).
+//
 // HBM-bound, and no random access anywhere: per element ~100 B of streamed traffic (first pass 12 + 12 read, 12 written;
 // second 8 + 12 read, 12 written; reduce 12 + 12 read) + 12 B written per destination.
 #include "common.h"
@@ -52,7 +58,7 @@ inline Layout1d layout1d(int64_t E, int64_t N) {
     l.vals_b = o; o += align_up((size_t)E * 4, 256);
     l.tile_hist = o; o += align_up(256 * tiles * 4, 256);
     l.digit_total = o; o += 256 * 4;
-    l.bptr = o; o += align_up((NB + 2) * 8, 256);
+    l.bptr = o; o += align_up(((size_t)gnnops_cdiv(N > 0 ? N : 1, 256) + 2) * 8, 256);   // sized for the finer (256-row) buckets of the sums
     l.desc = o; o += 256;
     l.total = o;
     return l;
@@ -60,21 +66,21 @@ inline Layout1d layout1d(int64_t E, int64_t N) {
 
 // the sentinel destination of ids outside [0, N): the first id past the last bucket (a bucket of its own, never reduced)
 inline int64_t sentinel_of(int64_t N) { return gnnops_cdiv(N, BUCKET) * BUCKET; }
-inline int passes_of(int64_t N) { return (bits_of(sentinel_of(N)) - LOW + 7) / 8; }
+inline int passes_of(int64_t N, int low = LOW) { return (bits_of(sentinel_of(N)) - low + 7) / 8; }
 
 template <typename T>
 __global__ void set_desc_kernel(sortengine::DstValSrc<T>* d, const int64_t* idx, const T* val, int64_t n_dst, uint32_t sentinel) {
     d->idx = idx; d->val = val; d->n_dst = n_dst; d->sentinel = sentinel;
 }
 
-// bptr[b] = first position whose (key >> 32) >> LOW >= b; bptr[NB] = first position of the sentinel bucket.
-__global__ void bounds1d_kernel(const uint64_t* __restrict__ keys, int64_t E, int64_t NB, int64_t* __restrict__ bptr) {
+// bptr[b] = first position whose (key >> 32) >> low >= b; bptr[NB] = first position of the sentinel bucket.
+__global__ void bounds1d_kernel(const uint64_t* __restrict__ keys, int64_t E, int64_t NB, int64_t* __restrict__ bptr, int low) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b > NB) return;
     int64_t lo = 0, hi = E;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)(keys[mid] >> (32 + LOW)) < b) lo = mid + 1; else hi = mid;
+        if ((int64_t)(keys[mid] >> (32 + low)) < b) lo = mid + 1; else hi = mid;
     }
     bptr[b] = lo;
 }
@@ -200,6 +206,155 @@ __global__ __launch_bounds__(RTHREADS) void minmax1d_kernel(const uint64_t* __re
     }
 }
 
+// ---- sums / means / products: buckets of 256 destinations, finished in source order -------------------------------------
+constexpr int SLOW = 8, SROWS = 1 << SLOW;      // destinations per bucket
+constexpr int STHREADS = 256, SWAVES = STHREADS / 64, SROUNDS = 4, SCAP = STHREADS * SROUNDS;   // pairs sorted on chip at a time: a bucket of the
+// reference shape holds ~256; four rounds keep the kernel at 64 registers, i.e. EIGHT workgroups per CU — the finish is a chain of
+// barriers and dependent LDS steps per bucket (5.75 M buckets), and what hides that latency is other buckets in flight
+
+// Stable counting sort, in LDS, of the n <= SCAP pairs at keys[cbeg .. cbeg + n) by (destination & 255): s_val gets the VALUE
+// bits grouped by destination in their original order, s_rowptr[0..256] the group boundaries (bucket.hip's sort_chunk with
+// the value instead of a position as payload). Ranking as in sort_engine_impl.h: per row of 64 pairs, eight ballots give every
+// lane its equal-key lanes; the lowest of them does ONE returning LDS add. Returns the size of group `threadIdx.x`.
+__device__ inline uint32_t sort_chunk64(const uint64_t* __restrict__ keys, int64_t cbeg, int n, uint32_t* s_val, uint32_t* s_whist,
+                                        int32_t* s_rowptr, uint32_t* s_tmp) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t* whist = s_whist + wave * 256;   // zeroed by the caller behind a barrier (sum1d_kernel: one barrier fewer per chunk)
+    const int rounds_n = (n + STHREADS - 1) / STHREADS;   // rows of 64 per wave
+    const int wave_base = wave * rounds_n * 64;
+    uint32_t dg[SROUNDS], vv[SROUNDS], rk[SROUNDS];
+    uint32_t is_leader = 0;
+#pragma unroll
+    for (int r = 0; r < SROUNDS; ++r) {
+        dg[r] = 0; vv[r] = 0; rk[r] = 0;
+        if (r < rounds_n) {
+            const int i = wave_base + r * 64 + lane;
+            const bool valid = i < n;
+            if (valid) {
+                const uint64_t k = keys[cbeg + i];
+                dg[r] = (uint32_t)(k >> 32) & (SROWS - 1);
+                vv[r] = (uint32_t)k;
+            }
+            const uint32_t d = dg[r];
+            const uint64_t m = match_digit8(d, __ballot(valid));   // valid lanes with my key
+            const uint32_t below = __popcll(m & lanes_below);
+            if (valid && below == 0) {
+                rk[r] = atomicAdd(&whist[d], (uint32_t)__popcll(m));  // rank of the group inside this wave
+                is_leader |= 1u << r;
+            } else {
+                rk[r] = below | ((uint32_t)(__ffsll((unsigned long long)m) - 1) << 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < SROUNDS; ++r) {
+        if (r < rounds_n) {
+            const bool lead = (is_leader >> r) & 1u;
+            const int from = lead ? lane : (int)((rk[r] >> 16) & 63u);
+            const uint32_t p = __shfl(rk[r], from);
+            rk[r] = lead ? p : p + (rk[r] & 0xffffu);
+        }
+    }
+    __syncthreads();
+    uint32_t tot = 0;   // key offsets: exclusive over waves, then over keys (thread d owns key d)
+#pragma unroll
+    for (int w = 0; w < SWAVES; ++w) {
+        const uint32_t c = s_whist[w * 256 + tid];
+        s_whist[w * 256 + tid] = tot;
+        tot += c;
+    }
+    // exclusive scan of `tot` over the 256 threads: wave scan, wave totals through s_tmp — ONE barrier (s_tmp is next written
+    // a chunk later, behind the caller's barriers)
+    const uint32_t incl = wave_incl_scan_u32(tot);
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t start = incl - tot;
+#pragma unroll
+    for (int w = 0; w < SWAVES; ++w)
+        if (w < wave) start += s_tmp[w];
+#pragma unroll
+    for (int w = 0; w < SWAVES; ++w) s_whist[w * 256 + tid] += start;
+    s_rowptr[tid] = (int32_t)start;
+    if (tid == SROWS - 1) s_rowptr[SROWS] = (int32_t)(start + tot);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SROUNDS; ++r) {
+        if (r < rounds_n) {
+            const int i = wave_base + r * 64 + lane;
+            if (i < n) s_val[whist[dg[r]] + rk[r]] = vv[r];
+        }
+    }
+    return tot;
+}
+
+// R: GNNOPS_SUM or GNNOPS_MUL; is_mean divides the sum by max(count, 1).
+template <typename T, int R>
+__global__ __launch_bounds__(STHREADS, 8) void sum1d_kernel(const uint64_t* __restrict__ keys, const int64_t* __restrict__ bptr,
+                                                         T* __restrict__ out, int64_t N, int64_t NB, int is_mean) {
+    __shared__ uint32_t s_val[SCAP];
+    __shared__ uint32_t s_whist[SWAVES * 256];
+    __shared__ int32_t s_rowptr[SROWS + 1];
+    __shared__ uint32_t s_tmp[SWAVES];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SWAVES * 256; i += STHREADS) s_whist[i] = 0;
+    for (int64_t b = blockIdx.x; b < NB; b += gridDim.x) {
+        const int64_t beg = bptr[b], end = bptr[b + 1];
+        float acc = Red<R>::identity();
+        uint32_t cnt = 0;
+        for (int64_t cbeg = beg; cbeg < end; cbeg += SCAP) {
+            const int n = (int)((end - cbeg < SCAP) ? (end - cbeg) : SCAP);
+            __syncthreads();   // the previous chunk's / bucket's readers are done with s_val, s_rowptr; s_whist is zero
+            cnt += sort_chunk64(keys, cbeg, n, s_val, s_whist, s_rowptr, s_tmp);
+            __syncthreads();   // everyone has placed its values (the last readers of s_whist)
+            for (int i = tid; i < SWAVES * 256; i += STHREADS) s_whist[i] = 0;   // for the next chunk, ordered by its leading barrier
+            const int32_t jb = s_rowptr[tid], je = s_rowptr[tid + 1];
+            for (int32_t j = jb; j < je; ++j) acc = Red<R>::apply(acc, __uint_as_float(s_val[j]));   // source order: chunks in order, stable inside
+        }
+        const int64_t d = (b << SLOW) + tid;
+        if (d < N) {
+            if (is_mean) acc = acc / (float)(cnt < 1 ? 1 : cnt);
+            Elem<T>::store(out + d, acc);
+        }
+    }
+}
+
+template <typename T>
+int run1d_sum(const void* src, const int64_t* index, void* out, int64_t E, int64_t N, int reduce, void* workspace, hipStream_t stream,
+              int (*first_pass)(const sortengine::DstValSrc<T>*, uint64_t*, uint32_t*, int64_t, int, uint32_t*, uint32_t*, int,
+                                hipStream_t)) {
+    const Layout1d l = layout1d(E, N);
+    char* w = (char*)workspace;
+    uint64_t* kbuf[2] = {(uint64_t*)(w + l.keys_a), (uint64_t*)(w + l.keys_b)};
+    uint32_t* vbuf[2] = {(uint32_t*)(w + l.vals_a), (uint32_t*)(w + l.vals_b)};
+    uint32_t* tile_hist = (uint32_t*)(w + l.tile_hist);
+    uint32_t* digit_total = (uint32_t*)(w + l.digit_total);
+    int64_t* bptr = (int64_t*)(w + l.bptr);
+    auto* desc = (sortengine::DstValSrc<T>*)(w + l.desc);
+    const int tiles = (int)gnnops_cdiv(E, sortengine::TILE);
+    const int64_t NB = gnnops_cdiv(N, SROWS);
+    const int64_t sentinel = NB * SROWS;                       // ids outside [0, N): a bucket of their own behind the last one
+    const int passes = (bits_of(sentinel) - SLOW + 7) / 8;
+    hipLaunchKernelGGL(set_desc_kernel<T>, dim3(1), dim3(1), 0, stream, desc, index, (const T*)src, N, (uint32_t)sentinel);
+    const uint64_t* kin = nullptr;
+    const uint32_t* vin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 32 + SLOW + 8 * p;
+        const int rc = p == 0 ? first_pass(desc, kbuf[0], vbuf[0], E, shift, tile_hist, digit_total, tiles, stream)
+                              : sortengine::pass_u64(kin, vin, kbuf[p & 1], vbuf[p & 1], E, shift, tile_hist, digit_total, tiles, stream);
+        if (rc != GNNOPS_OK) return rc;
+        kin = kbuf[p & 1]; vin = vbuf[p & 1];
+    }
+    hipLaunchKernelGGL(bounds1d_kernel, dim3((unsigned)gnnops_cdiv(NB + 1, 256)), dim3(256), 0, stream, kin, E, NB, bptr, SLOW);
+    const int grid = gnnops_grid_cap(NB, 256 * 16);
+    if (reduce == GNNOPS_MUL)
+        hipLaunchKernelGGL((sum1d_kernel<T, GNNOPS_MUL>), dim3(grid), dim3(STHREADS), 0, stream, kin, bptr, (T*)out, N, NB, 0);
+    else
+        hipLaunchKernelGGL((sum1d_kernel<T, GNNOPS_SUM>), dim3(grid), dim3(STHREADS), 0, stream, kin, bptr, (T*)out, N, NB,
+                           reduce == GNNOPS_MEAN ? 1 : 0);
+    return gnnops_check_launch("scatter1d_sum");
+}
+
 template <typename T>
 int run1d(const void* src, const int64_t* index, void* out, int64_t* arg_out, int64_t E, int64_t N, int reduce, void* workspace,
           hipStream_t stream, int (*first_pass)(const sortengine::DstValSrc<T>*, uint64_t*, uint32_t*, int64_t, int, uint32_t*, uint32_t*,
@@ -225,7 +380,7 @@ int run1d(const void* src, const int64_t* index, void* out, int64_t* arg_out, in
         kin = kbuf[p & 1]; vin = vbuf[p & 1];
     }
     const int64_t NB = gnnops_cdiv(N, BUCKET);
-    hipLaunchKernelGGL(bounds1d_kernel, dim3((unsigned)gnnops_cdiv(NB + 1, 256)), dim3(256), 0, stream, kin, E, NB, bptr);
+    hipLaunchKernelGGL(bounds1d_kernel, dim3((unsigned)gnnops_cdiv(NB + 1, 256)), dim3(256), 0, stream, kin, E, NB, bptr, LOW);
     const int grid = (int)(NB < 256 ? NB : 256);
     const size_t lds = (size_t)BUCKET * 4;
     static bool configured[2] = {false, false};
@@ -271,5 +426,29 @@ extern "C" int gnnops_scatter1d_minmax(const void* src, const int64_t* index, vo
             return run1d<__hip_bfloat16>(src, index, out, arg_out, E, N, reduce, workspace, stream, sortengine::pass_first_dstval_bf16);
     }
     gnnops_set_error("scatter1d_minmax: unknown dtype %d", dtype);
+    return GNNOPS_EINVAL;
+}
+
+// out[n] = sum / mean / product of src[e] over index[e] == n, in source position order (0 — 1 for a product — where nothing
+// arrives): bit-identical to the sequential loop. Same shape limits and workspace as gnnops_scatter1d_minmax.
+extern "C" int gnnops_scatter1d_sum(const void* src, const int64_t* index, void* out, int64_t E, int64_t N, int dtype, int reduce,
+                                    void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(E >= 0 && N >= 0, GNNOPS_EINVAL, "scatter1d_sum: negative size");
+    GNNOPS_REQUIRE(reduce == GNNOPS_SUM || reduce == GNNOPS_MEAN || reduce == GNNOPS_MUL, GNNOPS_EUNSUPPORTED,
+                   "scatter1d_sum: reduce %d (sum / mean / mul only)", reduce);
+    GNNOPS_REQUIRE(N > BUCKET && N < ((int64_t)1 << 31) - BUCKET && E > 0 && E < ((int64_t)1 << 31), GNNOPS_EUNSUPPORTED,
+                   "scatter1d_sum: shape outside this form (E=%lld N=%lld)", (long long)E, (long long)N);
+    GNNOPS_REQUIRE(src && index && out, GNNOPS_EINVAL, "scatter1d_sum: null pointer");
+    const Layout1d l = layout1d(E, N);
+    GNNOPS_REQUIRE(workspace && workspace_bytes >= l.total && (uintptr_t)workspace % 256 == 0, GNNOPS_EWORKSPACE,
+                   "scatter1d_sum: workspace %zu < %zu (or not 256-B aligned)", workspace_bytes, l.total);
+    hipStream_t stream = (hipStream_t)s;
+    switch (dtype) {
+        case GNNOPS_F32: return run1d_sum<float>(src, index, out, E, N, reduce, workspace, stream, sortengine::pass_first_dstval_f32);
+        case GNNOPS_F16: return run1d_sum<__half>(src, index, out, E, N, reduce, workspace, stream, sortengine::pass_first_dstval_f16);
+        case GNNOPS_BF16:
+            return run1d_sum<__hip_bfloat16>(src, index, out, E, N, reduce, workspace, stream, sortengine::pass_first_dstval_bf16);
+    }
+    gnnops_set_error("scatter1d_sum: unknown dtype %d", dtype);
     return GNNOPS_EINVAL;
 }

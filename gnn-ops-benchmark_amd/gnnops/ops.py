@@ -375,6 +375,17 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
         if rc != _lib.EUNSUPPORTED:
             check(rc, "scatter1d_minmax")
             return out, arg
+    if (not want_arg and init == 0 and row_index is not None and not is_plan and B == 1 and K == 1 and _SCATTER1D_MIN_N <= N < 2 ** 31 - 32768
+            and 0 < E < 2 ** 31):
+        # a long 1-D sum / mean / product: the same carried-value partial sort, one pass further (buckets of 256 destinations),
+        # finished on chip in source order — bit-identical to the sequential loop (scatter1d.hip)
+        ws_bytes = L.gnnops_scatter1d_workspace_bytes(E, N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
+        with torch.cuda.device(src.device):
+            rc = L.gnnops_scatter1d_sum(src.data_ptr(), row_index.data_ptr(), out.data_ptr(), E, N, dt, rcode, ws.data_ptr(), ws_bytes, _stream())
+        if rc != _lib.EUNSUPPORTED:
+            check(rc, "scatter1d_sum")
+            return out
     with torch.cuda.device(src.device):
         vec = 16 // src.element_size()
         rows_ok = K % vec == 0 and src.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0     # rows of whole 16-B lanes

@@ -193,6 +193,11 @@ int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_byte
 size_t gnnops_scatter1d_workspace_bytes(int64_t E, int64_t N);
 int gnnops_scatter1d_minmax(const void* src, const int64_t* index, void* out, int64_t* arg_out, int64_t E, int64_t N,
                             int dtype, int reduce, void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+/* The same shapes for reduce SUM / MEAN / MUL (benchmark_scatter_mean.py:15-18 at data/scatter_mean.csv:2): three passes to buckets
+ * of 256 destinations, finished by a stable on-chip sort and a sum in source position order — bit-identical to the sequential
+ * loop (16-bit types: fp32 accumulator, rounded once). Same workspace and shape limits as gnnops_scatter1d_minmax. */
+int gnnops_scatter1d_sum(const void* src, const int64_t* index, void* out, int64_t E, int64_t N, int dtype, int reduce,
+                         void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch.index_select (benchmark_native_index_select.py:12-15; also the first half of
