@@ -44,59 +44,73 @@ _SORT_1D_ONLY = (torch.int64, torch.float64)
 
 
 # ---- what the kernels take (pure predicates; no device work, no allocation) ---------------------------------------
-def _dense(t):
-    return (isinstance(t, torch.Tensor) and t.is_cuda and t.layout == torch.strided and not t.is_complex()
-            and not t.is_quantized and not t.is_conj() and not t.is_neg())
+# These run on EVERY call of a routed op, and at the reference's smallest shapes a call is host-bound (tools/host_overhead.py:
+# the first version of accepts_scatter cost 10 us of a 24-us call): plain attribute tests in cheapest-first order, no
+# generators. What the dispatcher already guarantees is not re-tested: a kernel on the CUDA key only sees strided, non-quantized
+# tensors with the conjugate / negative bits resolved (sparse, quantized and lazy-bit tensors carry other keys above it).
+# `get_device()` is -1 for a CPU tensor, so one comparison covers "on the GPU" and "on the SAME GPU".
+def _dev(t):
+    return t.get_device() if isinstance(t, torch.Tensor) else -2
 
 
 def _copyable(t):
-    return _dense(t) and t.element_size() in (1, 2, 4, 8)
-
-
-def _same_device(*ts):
-    return all(t.device == ts[0].device for t in ts)
+    return t.element_size() in (1, 2, 4, 8) and not t.is_complex()
 
 
 def _dim_ok(dim, ndim):
     return isinstance(dim, int) and ndim >= 1 and -ndim <= dim < ndim
 
 
+def _spans(index, self, d):
+    """index.size(k) == self.size(k) for every k != d"""
+    a, b = index.shape, self.shape
+    for k in range(len(b)):
+        if k != d and a[k] != b[k]:
+            return False
+    return True
+
+
 def accepts_index_select(self, dim, index):
-    return (_copyable(self) and _dense(index) and _same_device(self, index) and _dim_ok(dim, self.dim())
-            and index.dim() == 1 and index.dtype in (torch.int64, torch.int32) and self.is_contiguous()
-            and self.numel() > 0 and index.numel() > 0)
+    dv = _dev(self)
+    return (dv >= 0 and _dev(index) == dv and index.dim() == 1 and index.dtype in (torch.int64, torch.int32)
+            and _dim_ok(dim, self.dim()) and _copyable(self) and self.is_contiguous() and self.numel() > 0 and index.numel() > 0)
 
 
 def accepts_gather(self, dim, index, sparse_grad=False):
-    if not (_copyable(self) and _dense(index) and _same_device(self, index) and _dim_ok(dim, self.dim())
-            and index.dim() == self.dim() and index.dtype == torch.int64 and self.is_contiguous() and index.is_contiguous()
-            and self.numel() > 0 and index.numel() > 0):
+    dv = _dev(self)
+    nd = self.dim()
+    if not (dv >= 0 and _dev(index) == dv and index.dtype == torch.int64 and index.dim() == nd and _dim_ok(dim, nd)
+            and _copyable(self) and self.is_contiguous() and index.is_contiguous() and self.numel() > 0 and index.numel() > 0):
         return False
-    d = dim % self.dim()
-    return all(index.size(k) == self.size(k) for k in range(self.dim()) if k != d)
+    return _spans(index, self, dim % nd)
 
 
 def accepts_index_add(self, dim, index, source, alpha=1):
-    if not (_dense(self) and _dense(source) and _dense(index) and _same_device(self, index, source)
-            and self.dtype in _FLOATS and source.dtype == self.dtype and _is_one(alpha) and _dim_ok(dim, self.dim())
-            and source.dim() == self.dim() and index.dim() == 1 and index.dtype in (torch.int64, torch.int32)
-            and self.is_contiguous() and source.is_contiguous() and self.numel() > 0 and source.numel() > 0):
+    dv = _dev(self)
+    nd = self.dim()
+    if not (dv >= 0 and self.dtype in _FLOATS and _is_one(alpha) and _dev(index) == dv and _dev(source) == dv
+            and source.dtype == self.dtype and index.dtype in (torch.int64, torch.int32) and index.dim() == 1
+            and source.dim() == nd and _dim_ok(dim, nd) and self.is_contiguous() and source.is_contiguous()
+            and self.numel() > 0 and source.numel() > 0):
         return False
-    d = dim % self.dim()
-    return (index.numel() == source.size(d)
-            and all(source.size(k) == self.size(k) for k in range(self.dim()) if k != d))
+    d = dim % nd
+    return index.numel() == source.size(d) and _spans(source, self, d)
 
 
 def accepts_scatter(self, dim, index, src):
-    if not (_dense(self) and _dense(src) and _dense(index) and _same_device(self, index, src)
-            and self.dtype in _FLOATS and isinstance(src, torch.Tensor) and src.dtype == self.dtype
-            and _dim_ok(dim, self.dim()) and index.dtype == torch.int64
-            and index.dim() == self.dim() and src.dim() == self.dim() and self.is_contiguous()
-            and self.numel() > 0 and index.numel() > 0):
+    dv = _dev(self)
+    nd = self.dim()
+    if not (dv >= 0 and self.dtype in _FLOATS and _dev(index) == dv and _dev(src) == dv and src.dtype == self.dtype
+            and index.dtype == torch.int64 and index.dim() == nd and src.dim() == nd and _dim_ok(dim, nd)
+            and self.is_contiguous() and self.numel() > 0 and index.numel() > 0):
         return False
-    d = dim % self.dim()
-    return (all(index.size(k) == self.size(k) for k in range(self.dim()) if k != d)
-            and all(index.size(k) <= src.size(k) for k in range(self.dim())))
+    if not _spans(index, self, dim % nd):
+        return False
+    a, b = index.shape, src.shape
+    for k in range(nd):
+        if a[k] > b[k]:
+            return False
+    return True
 
 
 def accepts_scatter_reduce(self, dim, index, src, *, reduce):
@@ -104,24 +118,25 @@ def accepts_scatter_reduce(self, dim, index, src, *, reduce):
 
 
 def accepts_sort(self, dim=-1, descending=False, *, stable=None):
-    if not (_dense(self) and self.dtype in _SORT_DTYPES and _dim_ok(dim, self.dim()) and self.is_contiguous()
+    if not (_dev(self) >= 0 and self.dtype in _SORT_DTYPES and _dim_ok(dim, self.dim()) and self.is_contiguous()
             and self.numel() > 0):
         return False
     return self.dtype not in _SORT_1D_ONLY or self.numel() == self.size(dim)
 
 
 def _is_one(x):
-    return isinstance(x, (int, float)) and not isinstance(x, bool) and x == 1
+    return x == 1 and isinstance(x, (int, float)) and not isinstance(x, bool)
 
 
 def accepts_mm(self, mat2):
-    return (_dense(self) and _dense(mat2) and _same_device(self, mat2) and self.dtype in _FLOATS and mat2.dtype == self.dtype
-            and self.dim() == 2 and mat2.dim() == 2 and self.size(1) == mat2.size(0) and self.is_contiguous()
-            and mat2.is_contiguous() and self.numel() > 0 and mat2.numel() > 0)
+    dv = _dev(self)
+    return (dv >= 0 and self.dtype in _FLOATS and _dev(mat2) == dv and mat2.dtype == self.dtype and self.dim() == 2
+            and mat2.dim() == 2 and self.size(1) == mat2.size(0) and self.is_contiguous() and mat2.is_contiguous()
+            and self.numel() > 0 and mat2.numel() > 0)
 
 
 def accepts_addmm(self, mat1, mat2, *, beta=1, alpha=1):
-    if not (_is_one(beta) and _is_one(alpha) and _dense(self) and accepts_mm(mat1, mat2) and _same_device(self, mat1)
+    if not (_is_one(beta) and _is_one(alpha) and accepts_mm(mat1, mat2) and _dev(self) == _dev(mat1)
             and self.dtype == mat1.dtype and self.dim() in (1, 2) and self.is_contiguous()):
         return False
     M, N = mat1.size(0), mat2.size(1)
@@ -131,8 +146,8 @@ def accepts_addmm(self, mat1, mat2, *, beta=1, alpha=1):
 
 def accepts_clone(self, *, memory_format=None):
     """`m.transpose(0, 1).contiguous()` of a dense row-major 2-D matrix: the LDS tile transpose (csrc/sparse.hip)."""
-    return (memory_format == torch.contiguous_format and _copyable(self) and self.dim() == 2 and self.size(0) > 1
-            and self.size(1) > 1 and self.stride(0) == 1 and self.stride(1) == self.size(0))
+    return (memory_format is torch.contiguous_format and self.dim() == 2 and self.stride(0) == 1 and self.size(0) > 1
+            and self.size(1) > 1 and self.stride(1) == self.size(0) and _dev(self) >= 0 and _copyable(self))
 
 
 def _coo2(t, floats=True):
@@ -141,18 +156,20 @@ def _coo2(t, floats=True):
 
 
 def accepts_sparse_dense(sparse, dense):
-    return (_coo2(sparse) and _dense(dense) and dense.dim() == 2 and dense.dtype == sparse.dtype and dense.is_contiguous()
-            and sparse.size(1) == dense.size(0) and dense.numel() > 0 and _same_device(sparse, dense))
+    return (_coo2(sparse) and isinstance(dense, torch.Tensor) and dense.layout == torch.strided and dense.dim() == 2
+            and dense.dtype == sparse.dtype and dense.is_contiguous() and sparse.size(1) == dense.size(0) and dense.numel() > 0
+            and dense.get_device() == sparse.get_device())
 
 
 def accepts_sparse_addmm(self, mat1, mat2, *, beta=1, alpha=1):
     # torch.sparse.mm(S, D) lowers to addmm(zeros, S, D, beta=0, alpha=1) on the sparse key; nothing else is ours
-    return (isinstance(beta, (int, float)) and beta == 0 and _is_one(alpha) and _dense(self)
-            and accepts_sparse_dense(mat1, mat2))
+    return (isinstance(beta, (int, float)) and beta == 0 and _is_one(alpha) and isinstance(self, torch.Tensor)
+            and self.layout == torch.strided and accepts_sparse_dense(mat1, mat2))
 
 
 def accepts_sparse_sparse(self, other):
-    return _coo2(self) and _coo2(other) and self.dtype == other.dtype and self.size(1) == other.size(0) and _same_device(self, other)
+    return (_coo2(self) and _coo2(other) and self.dtype == other.dtype and self.size(1) == other.size(0)
+            and self.get_device() == other.get_device())
 
 
 def accepts_coalesce(self):

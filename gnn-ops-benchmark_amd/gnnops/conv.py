@@ -24,7 +24,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check
-from .ops import _dtype_code, _require_gpu, _stream, get_plan
+from .ops import _dtype_code, _on, _require_gpu, _stream, get_plan
 from .sparse import _coo_rows_cols, _csr_arrays
 
 FUNCTORS = {"copy": 0, "add": 1, "cgconv": 2, "film": 3}
@@ -104,7 +104,7 @@ def edge_reduce(functor, q, edge_index, num_dst, p=None, w=None, add=None, aggr=
     L = _lib.load()
     hub_bytes = L.gnnops_edge_reduce_hub_workspace_bytes(E, K)   # destinations with more than 8192 edges: reduced piecewise
     hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=q.device) if hub_bytes else None
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         rc = L.gnnops_edge_reduce_hubs(FUNCTORS[functor], ptr(q), ldq, ptr(p), ldp, ptr(w), ldw, ptr(add), ldadd,
                                        plan.rowptr.data_ptr(), plan.perm.data_ptr(), col.data_ptr(), out.data_ptr(), ldo,
                                        num_dst, E, K, c_aggr, len(aggr_ids), c_scal, len(scal_ids), avg_log, avg_lin, dt,
@@ -163,7 +163,7 @@ class _EdgeReduce(torch.autograd.Function):
         gp = torch.empty((E, 2 * K), dtype=g.dtype, device=g.device)
         gq = torch.empty((E, K), dtype=g.dtype, device=g.device) if ctx.functor == "film" else None
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-        with torch.cuda.device(g.device):
+        with _on(g.device):
             check(_lib.load().gnnops_edge_grad(FUNCTORS[ctx.functor], ptr(p_), ldp, ptr(q_), ldq, ptr(w_), ldw, g.data_ptr(), g.stride(0),
                                                src_rows.data_ptr(), dst_rows.data_ptr(), gp.data_ptr(), ptr(gq), E, K,
                                                _dtype_code(g, "edge_grad"), _stream()), "edge_grad")

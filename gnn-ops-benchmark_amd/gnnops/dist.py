@@ -63,12 +63,12 @@ class HipLocal:
     def owner_counts(self, index, per, world):
         """Device int64 [world]: how many of this rank's positions go to each owner's slab of `per` rows."""
         from . import _lib
-        from .ops import _require_gpu, _stream, check
+        from .ops import _on, _require_gpu, _stream, check
 
         _require_gpu(index)
         index = index.contiguous()
         counts = torch.empty(world, dtype=torch.int64, device=index.device)
-        with torch.cuda.device(index.device):
+        with _on(index.device):
             check(_lib.load().gnnops_owner_counts(index.data_ptr(), index.numel(), per, world, counts.data_ptr(), _stream()),
                   "owner_counts")
         return counts
@@ -83,7 +83,7 @@ class HipLocal:
         """Stage 1 of `route`: the windowed partition, enqueued BEFORE the host reads the owner counts back, so that the
         device is busy underneath that round trip. Returns the state `route` continues from."""
         from . import _lib
-        from .ops import _stream, check
+        from .ops import _on, _stream, check
 
         src, index = src.contiguous(), index.contiguous()
         E, n_loc = src.size(0), hi - lo
@@ -92,7 +92,7 @@ class HipLocal:
         L = _lib.load()
         ws_bytes = L.gnnops_bucket_workspace_bytes(E, n_loc)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
-        with torch.cuda.device(src.device):
+        with _on(src.device):
             check(L.gnnops_bucket_partition_window(index.data_ptr(), E, lo, n_loc, ws.data_ptr(), ws_bytes, _stream()),
                   "bucket_partition_window")
         return (src, index, ws)
@@ -105,7 +105,7 @@ class HipLocal:
         import ctypes
 
         from . import _lib
-        from .ops import _stream, check, index_select
+        from .ops import _on, _stream, check, index_select
         from .sparse import sort
 
         src, index, ws = state
@@ -137,7 +137,7 @@ class HipLocal:
                 return slab.zero_()
             hub_bytes = L.gnnops_hub_workspace_bytes(E, D, _lib.SUM)   # heavy destinations: csrc/hub.h
             hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=dev) if hub_bytes else None
-            with torch.cuda.device(dev):
+            with _on(dev):
                 check(L.gnnops_bucket_reduce_hubs(src.data_ptr(), ws.data_ptr(), slab.data_ptr(), None, E, D, n_loc, _lib.F32,
                                                   _lib.SUM, 0, hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes,
                                                   _stream()), "bucket_reduce")
@@ -250,7 +250,7 @@ class HipLocal:
         """out[i] = reduce over src[perm[crow[i] : crow[i+1]]] (crow int32: absolute positions into perm); ``arg`` (min /
         max) receives the position in src of each extremum."""
         from . import _lib
-        from .ops import REDUCE_CODE, _dtype_code, _stream, check
+        from .ops import REDUCE_CODE, _dtype_code, _on, _stream, check
 
         if n_rows == 0:
             return
@@ -259,7 +259,7 @@ class HipLocal:
         rcode = REDUCE_CODE["sum" if reduce == "add" else reduce]
         hub_bytes = L.gnnops_hub_workspace_bytes(E, D, rcode)   # heavy destinations: csrc/hub.h
         hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=src.device) if hub_bytes else None
-        with torch.cuda.device(src.device):
+        with _on(src.device):
             check(L.gnnops_segment_reduce_hubs(src.data_ptr(), crow.data_ptr(), perm.data_ptr(), out.data_ptr(),
                                                arg.data_ptr() if arg is not None else None, 1,
                                                E, D, n_rows, _dtype_code(src, "sharded_scatter"), rcode, 0,
@@ -275,7 +275,7 @@ class HipLocal:
         and ``finish(n_remote, n_lo)`` builds (ids, rows) once the caller has the numbers on the host (`sharded_spmm`: the one
         read-back it shares with the exchange of the counts)."""
         from . import _lib
-        from .ops import Plan, _dtype_code, _require_gpu, _stream, check
+        from .ops import Plan, _dtype_code, _on, _require_gpu, _stream, check
 
         _require_gpu(row, col, mat, value)
         if row.dim() != 1 or col.shape != row.shape or mat.dim() != 2:
@@ -296,7 +296,7 @@ class HipLocal:
         def mm(rp, n_rows, out):
             if n_rows == 0:
                 return
-            with torch.cuda.device(dev):
+            with _on(dev):
                 check(L.gnnops_spmm(rp.data_ptr(), perm.data_ptr(), col.data_ptr(),
                                     value.data_ptr() if value is not None else None, mat.data_ptr(), out.data_ptr(), n_rows,
                                     D, row.numel(), mat.size(0), dt, _stream()), "spmm")

@@ -26,8 +26,37 @@ from ._lib import F32, F16, BF16, REDUCE_CODE, check
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
 
+# At the reference's smallest shapes ((223, 223): benchmark_scatter_add.py:40-46) a call is host-bound: what the Timer sees is how
+# long Python takes to enqueue it. `torch.cuda.current_stream().cuda_stream` costs ~8 us and `with _on(d)` ~3 us
+# per use (device-index resolution in Python): the raw bindings below return the same values in ~0.3 us
+# (tools/host_overhead.py: torch_scatter.scatter_add at (223, 223) 43 -> 2x us per call).
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current stream of the current device, as the integer the C ABI takes."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class _Here:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_HERE = _Here()
+
+
+def _on(device):
+    """`with _on(t.device):` = `with _on(t.device):`, free when that device is the current one already."""
+    if _raw_device is not None and (device.index is None or device.index == _raw_device()):
+        return _HERE
+    return torch.cuda.device(device)
 
 
 def _require_gpu(*tensors):
@@ -113,7 +142,7 @@ class Plan:
             if companion is not None:
                 companion = companion.contiguous()
                 self.col = torch.empty(self.E, dtype=torch.int64, device=dev)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 rc = L.gnnops_plan_build_small(index.data_ptr(), companion.data_ptr() if companion is not None else None, self.E,
                                                self.N, self.rowptr.data_ptr(), self.perm.data_ptr(),
                                                self.col.data_ptr() if self.col is not None else None, _stream())
@@ -121,7 +150,7 @@ class Plan:
             return
         ws_bytes = L.gnnops_plan_workspace_bytes(self.E, self.N)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             rc = L.gnnops_plan_build(index.data_ptr(), self.E, self.N, self.rowptr.data_ptr(), self.perm.data_ptr(),
                                      ws.data_ptr(), ws_bytes, _stream())
         check(rc, "plan_build")
@@ -235,7 +264,7 @@ def _narrowed(index, full, bound):
     if hit[3] is None:
         nbytes = 2 if bound <= 65535 else 4             # 0xFFFF / -1 mark ids outside [0, bound): never a valid id
         narrow = torch.empty(full.shape, dtype=torch.int16 if nbytes == 2 else torch.int32, device=full.device)
-        with torch.cuda.device(full.device):
+        with _on(full.device):
             check(_lib.load().gnnops_narrow_index(full.data_ptr(), narrow.data_ptr(), full.numel(), nbytes, bound, _stream()), "narrow_index")
         hit[3] = (narrow, nbytes)
     return hit[3]
@@ -254,7 +283,7 @@ def index_max(index):
     _check_index(index, "index_max")
     index = index.contiguous()
     out = torch.empty(1, dtype=torch.int64, device=index.device)
-    with torch.cuda.device(index.device):
+    with _on(index.device):
         rc = _lib.load().gnnops_index_max(index.data_ptr(), index.numel(), out.data_ptr(), _stream())
     check(rc, "index_max")
     return int(out.item())
@@ -272,6 +301,8 @@ def _row_index_of(index, src, dim):
     if index.dim() == 1 and index.numel() == src.size(dim):
         return index.contiguous()
     if index.dim() == src.dim() and index.shape == src.shape:
+        if index.is_contiguous() and index.numel() != src.size(dim):
+            return None     # a contiguous full-shape index with more than one column is no broadcast (host time matters at small shapes)
         # index.view(-1,1).expand_as(src) and friends: stride 0 everywhere but `dim`
         if all(index.stride(d) == 0 or index.size(d) == 1 for d in range(index.dim()) if d != dim):
             sl = [0] * index.dim()
@@ -369,7 +400,7 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
         # sort and a workgroup finishes each bucket of 32768 destinations in LDS (scatter1d.hip) — no full sort, no random gather
         ws_bytes = L.gnnops_scatter1d_workspace_bytes(E, N)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
-        with torch.cuda.device(src.device):
+        with _on(src.device):
             rc = L.gnnops_scatter1d_minmax(src.data_ptr(), row_index.data_ptr(), out.data_ptr(), arg.data_ptr(), E, N, dt, rcode,
                                            ws.data_ptr(), ws_bytes, _stream())
         if rc != _lib.EUNSUPPORTED:
@@ -381,12 +412,12 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
         # finished on chip in source order — bit-identical to the sequential loop (scatter1d.hip)
         ws_bytes = L.gnnops_scatter1d_workspace_bytes(E, N)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
-        with torch.cuda.device(src.device):
+        with _on(src.device):
             rc = L.gnnops_scatter1d_sum(src.data_ptr(), row_index.data_ptr(), out.data_ptr(), E, N, dt, rcode, ws.data_ptr(), ws_bytes, _stream())
         if rc != _lib.EUNSUPPORTED:
             check(rc, "scatter1d_sum")
             return out
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         vec = 16 // src.element_size()
         rows_ok = K % vec == 0 and src.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0     # rows of whole 16-B lanes
         if row_index is not None and not is_plan and B == 1 and not _plan_cache_enabled and E > 0 and rows_ok and N > 256 and (
@@ -414,7 +445,7 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
                                               hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes, _stream())
             check(rc, "segment_reduce")
         else:
-            full = _broadcast_index(index, src, dim).contiguous()
+            full = index if (index.shape == src.shape and index.is_contiguous()) else _broadcast_index(index, src, dim).contiguous()
             ws_bytes = L.gnnops_scatter_elementwise_workspace_bytes(B, N, K, dt, rcode)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=src.device)
             ix, ix_bytes = _narrowed(index, full, N)
@@ -531,7 +562,7 @@ def index_select(input, dim, index, plan=None):
             # push form with no plan to keep: partition by bucket, finish the sort on chip inside the copy (bucket.hip)
             ws_bytes = L.gnnops_bucket_workspace_bytes(E, N)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
-            with torch.cuda.device(input.device):
+            with _on(input.device):
                 check(L.gnnops_bucket_partition(index.data_ptr(), E, N, ws.data_ptr(), ws_bytes, _stream()), "bucket_partition")
                 hub_bytes = L.gnnops_hub_workspace_bytes(E, 0, 0)   # hot rows are written by whole workgroups (hub.h)
                 hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=input.device) if hub_bytes else None
@@ -540,7 +571,7 @@ def index_select(input, dim, index, plan=None):
                       "bucket_select")
             return out
         plan = get_plan(index, N)
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         if plan is not None:
             if plan.E != E or plan.N != N:
                 raise ValueError("index_select: plan does not match index / input.size(dim)")
@@ -572,7 +603,7 @@ def gather(input, dim, index):
     B, N, K = _bek(input.shape, dim)
     E = index.size(dim)
     out = torch.empty(index.shape, dtype=input.dtype, device=input.device)
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         rc = _lib.load().gnnops_gather(input.data_ptr(), index.data_ptr(), out.data_ptr(), B, N, K, E, eb, _stream())
     check(rc, "gather")
     return out
@@ -621,7 +652,7 @@ def index_select_sum(input, dim, index):
     out = torch.empty((), dtype=torch.float32, device=input.device)
     ws_bytes = L.gnnops_fused_select_sum_workspace_bytes()
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         rc = L.gnnops_fused_index_select_sum(input.data_ptr(), index.data_ptr(), out.data_ptr(), B, N, K,
                                              index.numel(), dt, ws.data_ptr(), ws_bytes, _stream())
     check(rc, "fused_index_select_sum")
@@ -655,7 +686,7 @@ def index_add_select_sum(input, dim, index, other):
     L = _lib.load()
     ws_bytes = L.gnnops_fused_index_add_select_sum_workspace_bytes(B, K)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=input.device)
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         rc = L.gnnops_fused_index_add_select_sum(input.data_ptr(), other.data_ptr(), plan.rowptr.data_ptr(),
                                                  plan.perm.data_ptr(), out.data_ptr(), B, N, E, K, dt, ws.data_ptr(),
                                                  ws_bytes, _stream())
@@ -694,7 +725,7 @@ def addmm(input, mat1, mat2, *, beta=1, alpha=1):
     L = _lib.load()
     ws_bytes = L.gnnops_addmm_workspace_bytes(M, N, K)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat1.device) if ws_bytes else None
-    with torch.cuda.device(mat1.device):
+    with _on(mat1.device):
         rc = L.gnnops_addmm_ld(input.data_ptr() if input is not None else None, ld_input, mat1.data_ptr(), mat2.data_ptr(),
                                out.data_ptr(), M, N, K, dt, ws.data_ptr() if ws is not None else None, ws_bytes, _stream())
     check(rc, "addmm")

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import REDUCE_CODE, check
-from .ops import Plan, _bek, _check_index, _dtype_code, _norm_dim, _require_gpu, _row_index_of, _stream, get_plan
+from .ops import Plan, _bek, _check_index, _dtype_code, _norm_dim, _on, _require_gpu, _row_index_of, _stream, get_plan
 
 _MODES = {"softmax": 0, "log_softmax": 1, "logsumexp": 2, "std": 3}
 
@@ -37,7 +37,7 @@ def _reduce_over(plan, src, dim, reduce, want_arg):
     shape[dim] = plan.N
     out = torch.empty(shape, dtype=src.dtype, device=src.device)
     arg = torch.empty(shape, dtype=torch.int64, device=src.device) if want_arg else None
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         rc = _lib.load().gnnops_segment_reduce(src.data_ptr(), plan.rowptr.data_ptr(),
                                                plan.perm.data_ptr() if plan.perm is not None else None, out.data_ptr(),
                                                arg.data_ptr() if arg is not None else None, B, E, K, plan.N, dt, rcode, 0,
@@ -76,7 +76,7 @@ def expand_rowptr(indptr, E):
     _require_gpu(indptr)
     rowptr = _as_int32_rowptr(indptr)
     index = torch.empty(E, dtype=torch.int64, device=indptr.device)
-    with torch.cuda.device(indptr.device):
+    with _on(indptr.device):
         check(_lib.load().gnnops_rowptr_expand(rowptr.data_ptr(), rowptr.numel() - 1, E, index.data_ptr(), _stream()),
               "rowptr_expand")
     return index
@@ -91,7 +91,7 @@ def rowptr_from_sorted(index, N):
     rowptr = torch.empty(N + 1, dtype=torch.int32, device=index.device)
     ws_bytes = L.gnnops_rowptr_workspace_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=index.device)
-    with torch.cuda.device(index.device):
+    with _on(index.device):
         check(L.gnnops_rowptr_from_sorted(index.data_ptr(), index.numel(), N, rowptr.data_ptr(), ws.data_ptr(), ws_bytes,
                                           _stream()), "rowptr_from_sorted")
     return rowptr
@@ -182,7 +182,7 @@ def _composite(src, index, dim, dim_size, mode, param):
     L = _lib.load()
     hub_bytes = L.gnnops_hub_workspace_bytes(E, K, _lib.MIN) if B == 1 else 0   # groups with more than 8192 members: hub.h
     hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=src.device) if hub_bytes else None
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         rc = L.gnnops_segment_composite_hubs(src.data_ptr(), plan.rowptr.data_ptr(),
                                              plan.perm.data_ptr() if plan.perm is not None else None, out.data_ptr(),
                                              B, E, K, plan.N, dt, _MODES[mode], float(param),

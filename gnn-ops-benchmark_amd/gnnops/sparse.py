@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .ops import Plan, _check_index, _dtype_code, _norm_dim, _bek, _require_gpu, _stream, get_plan
+from .ops import Plan, _check_index, _dtype_code, _norm_dim, _bek, _on, _require_gpu, _stream, get_plan
 
 
 def _coo_rows_cols(index, what):
@@ -85,7 +85,7 @@ def sddmm(rows_a, rows_b, a, b):
     dt = _dtype_code(a, "sddmm")
     rows_a, rows_b, a, b = rows_a.contiguous(), rows_b.contiguous(), a.contiguous(), b.contiguous()
     out = torch.empty(rows_a.numel(), dtype=a.dtype, device=a.device)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         check(_lib.load().gnnops_sddmm(rows_a.data_ptr(), rows_b.data_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(),
                                        rows_a.numel(), a.size(1), dt, _stream()), "sddmm")
     return out
@@ -107,7 +107,7 @@ def spmm_csr(rowptr, col, value, matrix):
 
 def _permute(t, perm, n):
     out = torch.empty(n, dtype=t.dtype, device=t.device)
-    with torch.cuda.device(t.device):
+    with _on(t.device):
         check(_lib.load().gnnops_permute(t.data_ptr(), perm.data_ptr(), out.data_ptr(), n, t.element_size(), _stream()), "permute")
     return out
 
@@ -152,7 +152,7 @@ def _spmm_launch(rowptr, perm, col, value, matrix, m, dt, plan=None, owner=None,
     L = _lib.load()
     hub_bytes = L.gnnops_hub_workspace_bytes(col.numel(), D, 0)   # rows with more than 8192 nonzeros: csrc/hub.h
     hub_ws = torch.empty(hub_bytes, dtype=torch.uint8, device=matrix.device) if hub_bytes else None
-    with torch.cuda.device(matrix.device):
+    with _on(matrix.device):
         rc = L.gnnops_spmm_hubs(rowptr.data_ptr(), perm.data_ptr() if perm is not None else None, col.data_ptr(),
                                 value_c.data_ptr() if value_c is not None else None, matrix.data_ptr(),
                                 out.data_ptr(), m, D, col.numel(), matrix.size(0), dt,
@@ -190,7 +190,7 @@ def spspmm(indexA, valueA, indexB, valueB, m, k, n, coalesced=False):
     ws_bytes = L.gnnops_spspmm_workspace_bytes(nnzA)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     total = torch.empty(1, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(L.gnnops_spspmm_count(colA.data_ptr(), nnzA, planB.rowptr.data_ptr(), total.data_ptr(), ws.data_ptr(),
                                     ws_bytes, _stream()), "spspmm_count")
         P = int(total.item())
@@ -227,7 +227,7 @@ def coalesce(index, value, m, n, op="add"):
     count = torch.empty(1, dtype=torch.int64, device=dev)
     ws_bytes = L.gnnops_coalesce_workspace_bytes(nnz)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = L.gnnops_coalesce(row.data_ptr(), col.data_ptr(), value_c.data_ptr() if value_c is not None else None, nnz,
                                m, n, C, dt, out_index[0].data_ptr(), out_index[1].data_ptr(),
                                out_value.data_ptr() if out_value is not None else None, count.data_ptr(),
@@ -267,7 +267,7 @@ def transpose_contiguous(mat):
     mat = mat.contiguous()
     R, C = mat.shape
     out = torch.empty((C, R), dtype=mat.dtype, device=mat.device)
-    with torch.cuda.device(mat.device):
+    with _on(mat.device):
         rc = _lib.load().gnnops_transpose2d(mat.data_ptr(), out.data_ptr(), R, C, eb, _stream())
     check(rc, "transpose2d")
     return out
@@ -277,7 +277,7 @@ def _transpose_batched(t3):
     """[B, R, C] -> [B, C, R] contiguous (any 1/2/4/8-byte dtype)."""
     Bn, R, C = t3.shape
     out = torch.empty((Bn, C, R), dtype=t3.dtype, device=t3.device)
-    with torch.cuda.device(t3.device):
+    with _on(t3.device):
         check(_lib.load().gnnops_transpose_batched(t3.data_ptr(), out.data_ptr(), Bn, R, C, t3.element_size(), _stream()),
               "transpose_batched")
     return out
@@ -288,7 +288,7 @@ def _sort_rows(mat, descending, out_shape):
     values = torch.empty(out_shape, dtype=torch.float32, device=mat.device)
     indices = torch.empty(out_shape, dtype=torch.int64, device=mat.device)
     L = _lib.load()
-    with torch.cuda.device(mat.device):
+    with _on(mat.device):
         if E <= L.gnnops_sort_rows_max_len():
             check(L.gnnops_sort_rows_f32(mat.data_ptr(), values.data_ptr(), indices.data_ptr(), rows, E,
                                          1 if descending else 0, _stream()), "sort_rows")
@@ -329,7 +329,7 @@ def sort(input, dim=-1, descending=False, stable=False):
     indices = torch.empty(input.shape, dtype=torch.int64, device=input.device)
     ws_bytes = L.gnnops_sort_workspace_bytes(B, E, K, sd)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=input.device)
-    with torch.cuda.device(input.device):
+    with _on(input.device):
         rc = L.gnnops_sort(input.data_ptr(), values.data_ptr(), indices.data_ptr(), B, E, K, sd, 1 if descending else 0,
                            ws.data_ptr(), ws_bytes, _stream())
     check(rc, "sort")

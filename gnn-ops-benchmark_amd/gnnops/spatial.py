@@ -11,7 +11,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check
-from .ops import _dtype_code, _require_gpu, _stream, get_plan
+from .ops import _dtype_code, _on, _require_gpu, _stream, get_plan
 from .sparse import _csr_arrays
 
 
@@ -52,7 +52,7 @@ def spline_basis(pseudo, kernel_size, is_open_spline, degree):
     S = (degree + 1) ** D
     basis = torch.empty((E, S), dtype=pseudo.dtype, device=pseudo.device)
     wi = torch.empty((E, S), dtype=torch.int64, device=pseudo.device)
-    with torch.cuda.device(pseudo.device):
+    with _on(pseudo.device):
         check(_lib.load().gnnops_spline_basis(pseudo.data_ptr(), ks.data_ptr(), op.data_ptr(), E, D, int(degree), basis.data_ptr(),
                                               wi.data_ptr(), dt, _stream()), "spline_basis")
     return basis, wi
@@ -71,7 +71,7 @@ def spline_weighting(x, weight, basis, weight_index):
     E, Min = x.shape
     Mout = weight.size(2)
     out = torch.empty((E, Mout), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.load().gnnops_spline_weighting(x.data_ptr(), weight.data_ptr(), basis.data_ptr(), weight_index.data_ptr(),
                                                   out.data_ptr(), E, Min, Mout, basis.size(1), dt, _stream()), "spline_weighting")
     return out
@@ -113,7 +113,7 @@ def spline_conv(x, edge_index, pseudo, weight, kernel_size, is_open_spline, degr
     ptr = lambda t: t.contiguous().data_ptr() if t is not None else None   # noqa: E731
     root_c = root_weight.contiguous() if root_weight is not None else None
     bias_c = bias.contiguous() if bias is not None else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.load().gnnops_spline_conv(x.data_ptr(), plan.rowptr.data_ptr(), plan.perm.data_ptr(), src.data_ptr(), pseudo.data_ptr(),
                                              weight.data_ptr(), ks.data_ptr(), op.data_ptr(), D, int(degree), ptr(root_c), ptr(bias_c),
                                              out.data_ptr(), N, E, Min, Mout, 1 if norm else 0, dt, _stream()), "spline_conv")
@@ -156,7 +156,7 @@ def grid_cluster(pos, size, start=None, end=None):
     if not (size.numel() == start.numel() == end.numel() == D):
         raise RuntimeError("grid_cluster: size, start and end need one entry per coordinate")
     out = torch.empty(N, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().gnnops_grid_cluster(pos.data_ptr(), N, D, size.data_ptr(), start.contiguous().data_ptr(), end.contiguous().data_ptr(),
                                               out.data_ptr(), dt, _stream()), "grid_cluster")
     return out
@@ -183,7 +183,7 @@ def fps(x, batch=None, ratio=0.5, random_start=True):
         start = ptr[:-1].clone()
     out = torch.empty(total, dtype=torch.int64, device=dev)
     dist = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().gnnops_fps(x.data_ptr(), ptr.data_ptr(), out_ptr.data_ptr(), start.data_ptr(), ptr.numel() - 1, D, dist.data_ptr(),
                                      out.data_ptr(), dt, _stream()), "fps")
     return out
@@ -216,7 +216,7 @@ def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
     dt = _dtype_code(x, "knn")
     ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
     col = torch.empty((y.size(0), k), dtype=torch.int64, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.load().gnnops_knn(x.data_ptr(), y.data_ptr(), ptr_x.data_ptr(), ptr_y.data_ptr(), ptr_x.numel() - 1, y.size(0), x.size(1),
                                      int(k), 1 if cosine else 0, col.data_ptr(), dt, _stream()), "knn")
     return _pairs(col, k)
@@ -242,7 +242,7 @@ def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32, num_worker
     dt = _dtype_code(x, "radius")
     ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
     col = torch.empty((y.size(0), max_num_neighbors), dtype=torch.int64, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.load().gnnops_radius(x.data_ptr(), y.data_ptr(), ptr_x.data_ptr(), ptr_y.data_ptr(), ptr_x.numel() - 1, y.size(0), x.size(1),
                                         float(r), int(max_num_neighbors), col.data_ptr(), dt, _stream()), "radius")
     return _pairs(col, max_num_neighbors)
@@ -266,7 +266,7 @@ def nearest(x, y, batch_x=None, batch_y=None):
     dt = _dtype_code(x, "nearest")
     ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
     col = torch.empty((x.size(0), 1), dtype=torch.int64, device=x.device)
-    with torch.cuda.device(x.device):   # the k = 1 search with the roles swapped: queries are x, candidates y
+    with _on(x.device):   # the k = 1 search with the roles swapped: queries are x, candidates y
         check(_lib.load().gnnops_knn(y.data_ptr(), x.data_ptr(), ptr_y.data_ptr(), ptr_x.data_ptr(), ptr_x.numel() - 1, x.size(0), x.size(1),
                                      1, 0, col.data_ptr(), dt, _stream()), "nearest")
     return col.view(-1)
@@ -302,7 +302,7 @@ def random_walk(row, col, start, walk_length, p=1.0, q=1.0, coalesced=True, num_
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     colc = col.contiguous() if col.numel() else torch.zeros(1, dtype=torch.int64, device=row.device)
-    with torch.cuda.device(row.device):
+    with _on(row.device):
         if biased:
             check(_lib.load().gnnops_random_walk_node2vec(rowptr.data_ptr(), colc.data_ptr(), start.data_ptr(), start.numel(), int(walk_length),
                                                           float(p), float(q), int(seed), out.data_ptr(), _stream()), "random_walk_node2vec")
@@ -341,13 +341,13 @@ def graclus_cluster(row, col, weight=None, num_nodes=None, seed=None):
     active = torch.zeros(1, dtype=torch.int32, device=dev)
     L = _lib.load()
     while True:
-        with torch.cuda.device(dev):
+        with _on(dev):
             check(L.gnnops_graclus_rounds(rowptr.data_ptr(), colc.data_ptr(), w_csr.data_ptr() if w_csr is not None else None, num_nodes,
                                           int(seed), 8, cluster.data_ptr(), proposal.data_ptr(), active.data_ptr(), 0, dt, _stream()),
                   "graclus_cluster")
         if int(active) == 0:
             break
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(L.gnnops_graclus_rounds(rowptr.data_ptr(), colc.data_ptr(), None, num_nodes, int(seed), 0, cluster.data_ptr(),
                                       proposal.data_ptr(), active.data_ptr(), 1, dt, _stream()), "graclus_cluster")
     return cluster
