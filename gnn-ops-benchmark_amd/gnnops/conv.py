@@ -15,8 +15,9 @@ differentiable — the dense products through gnnops.autograd.addmm, the edge pa
 is the forward's own machinery run the other way: the output gradient gathered along the TRANSPOSED plan (copy messages), or
 one streaming kernel that writes the per-edge gradient of the message (gnnops_edge_grad: cgconv / film) followed by two
 segment sums over the plans the forward already holds (by destination for the p side, by source for the q side). Packed
-weight operands are cached only while nothing requires grad. PNAConv (min / max / std aggregators with degree scalers)
-stays forward-only: its parameters are frozen when it is built and a call that would need a gradient raises.
+weight operands are cached only while nothing requires grad. PNAConv (min / max / std aggregators with degree scalers): the
+fused multi-aggregator pass has no backward, so in a graph that needs gradients the layer runs the propagate-order chain
+(`_forward_train`: per-edge messages, one differentiable scatter per aggregator) on this package's differentiable ops.
 """
 import ctypes
 
@@ -237,7 +238,7 @@ def _pair(x):
 
 
 class _Layer(torch.nn.Module):
-    """GIN / SAGE / CGConv / FiLM are trainable (module docstring); `_freeze` / `_forward_only` are what PNAConv uses."""
+    """Every layer is trainable (module docstring); `_freeze` / `_forward_only` remain for callers that want an inference-only copy."""
 
     def _freeze(self):
         self.requires_grad_(False)
@@ -413,7 +414,8 @@ class PNAConv(_Layer):
     """Principal neighbourhood aggregation (torch_geometric PNAConv; benchmark_convs.py:197-206: in 1, out 2048,
     aggregators mean/min/max/std, scalers identity/amplification/attenuation, deg = in-degree histogram).
     message = pre_nn([x_i, x_j (, enc(e))]) with ONE pre-layer is p_i + q_j (+ w_e); the aggregators and scalers come out of
-    one edge pass, written next to x into the [N, (1 + A S) F] operand of the post layer. pre_layers > 1: the first layer is
+    one edge pass, written next to x into the [N, (1 + A S) F] operand of the post layer (inference; when a gradient is needed
+    the layer runs `_forward_train`: the same mathematics as a chain of this package's differentiable ops). pre_layers > 1: the first layer is
     still split per node, the rest of the MLP runs on per-edge rows (see forward); post_layers > 1: more node-row products."""
 
     def __init__(self, in_channels, out_channels, aggregators, scalers, deg, edge_dim=None, towers=1, pre_layers=1,
@@ -448,15 +450,61 @@ class PNAConv(_Layer):
         self.post_nns = torch.nn.ModuleList([mlp(width, self.F_out, post_layers) for _ in range(towers)])
         self.lin = torch.nn.Linear(out_channels, out_channels)
         self._pk = {}
-        self._freeze()
 
     def _cache(self, name):
         if name not in self._pk:
             self._pk[name] = _Packed()
         return self._pk[name]
 
+    def _forward_train(self, x, edge_index, edge_attr):
+        """In a graph that needs gradients: the propagate-order chain — per-edge messages [E, F], one differentiable scatter per
+        aggregator (min / max route the gradient to their arg, std through its two means), the degree scalers as constant
+        factors — built from the differentiable front ends of this package's own kernels (gnnops.autograd: index_select,
+        scatter, addmm). The fused multi-aggregator edge pass has no backward; inference keeps it."""
+        from . import autograd as ad
+
+        F, T = self.F_in, self.towers
+        n = x.size(0)
+        src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+        xt = x.view(n, T, F) if self.divide_input else x.view(n, 1, F).expand(n, T, F)
+
+        def lin(z, layer):
+            return ad.addmm(layer.bias, z.contiguous(), layer.weight.t().contiguous())
+
+        def mlp(z, seq):
+            z = lin(z, seq[0])
+            for li in range(1, (len(seq) + 1) // 2):
+                z = lin(torch.relu(z), seq[2 * li])
+            return z
+
+        e = lin(edge_attr, self.edge_encoder) if self.edge_dim is not None else None
+        deg = ad.scatter(torch.ones(dst.numel(), 1, dtype=x.dtype, device=x.device), dst, 0, None, n, "sum").clamp_(min=1)
+        logd = torch.log(deg + 1)
+        fac = {"identity": None, "amplification": logd / self.avg_deg["log"], "attenuation": self.avg_deg["log"] / logd,
+               "linear": deg / self.avg_deg["lin"], "inverse_linear": self.avg_deg["lin"] / deg}
+        outs = []
+        for t in range(T):
+            xin = xt[:, t].contiguous()
+            z = [ad.index_select(xin, 0, dst), ad.index_select(xin, 0, src)] + ([e] if e is not None else [])
+            m = mlp(torch.cat(z, dim=1), self.pre_nns[t])
+            aggs = []
+            for a in self.aggregators:
+                if a == "std":
+                    mean = ad.scatter(m, dst, 0, None, n, "mean")
+                    aggs.append(torch.sqrt(torch.relu(ad.scatter(m * m, dst, 0, None, n, "mean") - mean * mean) + 1e-5))
+                else:
+                    r = ad.scatter(m, dst, 0, None, n, "sum" if a == "add" else a)
+                    aggs.append(r[0] if isinstance(r, tuple) else r)
+            out = torch.cat(aggs, dim=1)
+            out = torch.cat([out if fac[sc] is None else out * fac[sc] for sc in self.scalers], dim=1) if self.scalers else out
+            outs.append(mlp(torch.cat([xin, out], dim=1), self.post_nns[t]))
+        return lin(outs[0] if T == 1 else torch.cat(outs, dim=1), self.lin)
+
     def forward(self, x, edge_index, edge_attr=None):
-        self._forward_only(x, edge_attr)
+        if self.edge_dim is not None and edge_attr is None:
+            raise RuntimeError("PNAConv: edge_attr is required when edge_dim is set")
+        if _wants_grad(x, edge_attr, *self.parameters()):
+            return self._forward_train(x, edge_index, edge_attr)
         F, T = self.F_in, self.towers
         n = x.size(0)
         xt = x.view(n, T, F) if self.divide_input else x.view(n, 1, F).expand(n, T, F)

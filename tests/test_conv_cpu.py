@@ -35,8 +35,7 @@ def test_layer_parameter_names_and_shapes_follow_pyg():
                            "post_nns.0.0.bias": (2048,), "lin.weight": (2048, 2048), "lin.bias": (2048,)}
     assert pna.avg_deg["lin"] == pytest.approx((3 * 1 + 5 * 2 + 2 * 3) / 10) and pna.avg_deg["log"] == pytest.approx(
         (3 * np.log(2) + 5 * np.log(3) + 2 * np.log(4)) / 10)
-    assert not any(p.requires_grad for p in pna.parameters()), "PNAConv is forward-only: its parameters are frozen when it is built"
-    assert all(p.requires_grad for p in conv.CGConv(4).parameters()), "CGConv / GIN / SAGE / FiLM are trainable"
+    assert all(p.requires_grad for p in pna.parameters()) and all(p.requires_grad for p in conv.CGConv(4).parameters()), "every layer is trainable"
     deep = conv.PNAConv(4, 8, ["mean"], ["identity"], torch.tensor([1, 1]), pre_layers=2, post_layers=3)      # PyG's module layout
     assert set(shapes(deep)) >= {"pre_nns.0.0.weight", "pre_nns.0.2.weight", "post_nns.0.0.weight", "post_nns.0.2.weight", "post_nns.0.4.bias"}
     with pytest.raises(ValueError):

@@ -376,10 +376,10 @@ def test_pna_conv_deeper_pre_and_post_networks(conv, ora, pre, post, edge):
     _close(got, want, torch.float32, f"PNA pre={pre} post={post}")
 
 
-def test_pna_is_forward_only_and_the_others_join_the_graph(conv):
-    """groq_script.py:135-137 warms the model up OUTSIDE torch.no_grad(). GIN / SAGE / CGConv / FiLM are differentiable
-    (tests/test_conv_train_gpu.py): such a call returns a result attached to the graph. PNAConv (min / max / std with degree
-    scalers) is forward-only: its parameters are frozen when it is built, and asking it for a gradient is refused, not dropped."""
+def test_layers_join_the_graph_outside_no_grad(conv):
+    """groq_script.py:135-137 warms the model up OUTSIDE torch.no_grad(): every layer is differentiable
+    (tests/test_conv_train_gpu.py), so such a call returns a result attached to the graph; under no_grad / with frozen
+    parameters the fused inference pass runs and the result is detached."""
     layer = conv.CGConv(11, 0).half().cuda()
     x = torch.rand(29, 11, device="cuda").half()
     ei = torch.randint(0, 29, (2, 56), device="cuda")
@@ -388,14 +388,14 @@ def test_pna_is_forward_only_and_the_others_join_the_graph(conv):
     with torch.no_grad():
         assert not layer(x, ei).requires_grad
     pna = conv.PNAConv(4, 8, ["mean", "max"], ["identity"], torch.tensor([0, 3, 5, 2])).cuda()
-    assert not any(p.requires_grad for p in pna.parameters())
     xp = torch.rand(29, 4, device="cuda")
-    assert not pna(xp, ei).requires_grad   # grad mode on, nothing requires grad
-    pna.lin.weight.requires_grad_(True)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        pna(xp, ei)
+    assert pna(xp, ei).requires_grad
     with torch.no_grad():
-        pna(xp, ei)
+        fused = pna(xp, ei)
+    assert not fused.requires_grad
+    torch.testing.assert_close(pna(xp, ei).detach(), fused, rtol=1e-4, atol=1e-5)     # the train chain == the fused pass
+    pna.requires_grad_(False)
+    assert not pna(xp, ei).requires_grad   # frozen: the fused pass, grad mode on
 
 
 def test_layers_under_inference_mode(conv, ora):

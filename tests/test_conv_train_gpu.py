@@ -173,6 +173,58 @@ def test_film_gradients(conv, dtype, relations, aggr):
     _compare(layer, run_dev, run_ref, {"x": _rand(g, n, 12)}, TOLS[dtype] * (3 if dtype == torch.float16 else 1))
 
 
+@pytest.mark.parametrize("cfg", [dict(i=8, o=24, towers=2, edge=None, divide=False, pre=1, post=1),
+                                 dict(i=16, o=32, towers=4, edge=3, divide=True, pre=2, post=2)])
+def test_pna_gradients(conv, cfg):
+    """PNAConv (mean / min / max / std x identity / amplification / attenuation): in a graph that needs gradients the layer
+    runs the propagate-order chain on this package's differentiable ops; against torch-CPU float64 autograd of the same
+    chain (PyG 2.0.2 definitions: parity unpinned). Random float messages: min / max have unique arguments."""
+    torch.manual_seed(6)
+    n, e, T = 300, 2400, cfg["towers"]
+    ei = _graph(8, n, e)
+    deg_hist = torch.bincount(torch.bincount(ei[1], minlength=n))
+    aggr, scal = ["mean", "min", "max", "std"], ["identity", "amplification", "attenuation"]
+    layer = conv.PNAConv(cfg["i"], cfg["o"], aggr, scal, deg_hist, edge_dim=cfg["edge"], towers=T, divide_input=cfg["divide"],
+                         pre_layers=cfg["pre"], post_layers=cfg["post"]).cuda()
+    g = torch.Generator().manual_seed(10)
+    inputs = {"x": _rand(g, n, cfg["i"])}
+    if cfg["edge"]:
+        inputs["ea"] = _rand(g, e, cfg["edge"])
+    F = cfg["i"] // T if cfg["divide"] else cfg["i"]
+    avg = layer.avg_deg
+
+    def run_dev(layer, x, ea=None):
+        return layer(x, ei.cuda(), ea)
+
+    def mlp(P, name, z, layers):
+        z = z @ P[f"{name}.0.weight"].t() + P[f"{name}.0.bias"]
+        for li in range(1, layers):
+            z = torch.relu(z) @ P[f"{name}.{2 * li}.weight"].t() + P[f"{name}.{2 * li}.bias"]
+        return z
+
+    def run_ref(P, x, ea=None):
+        src, dst = ei
+        xt = x.view(n, T, F) if cfg["divide"] else x.view(n, 1, F).expand(n, T, F)
+        en = ea @ P["edge_encoder.weight"].t() + P["edge_encoder.bias"] if ea is not None else None
+        deg = torch.bincount(dst, minlength=n).clamp(min=1).double().unsqueeze(1)
+        outs = []
+        for t in range(T):
+            xin = xt[:, t]
+            m = mlp(P, f"pre_nns.{t}", torch.cat([xin[dst], xin[src]] + ([en] if en is not None else []), -1), cfg["pre"])
+            mean = _scatter64(m, dst, n, "mean")
+            mn = torch.full((n, F), float("inf"), dtype=torch.float64).scatter_reduce(0, dst.view(-1, 1).expand(-1, F), m, "amin", include_self=True)
+            mx = torch.full((n, F), float("-inf"), dtype=torch.float64).scatter_reduce(0, dst.view(-1, 1).expand(-1, F), m, "amax", include_self=True)
+            has = (torch.bincount(dst, minlength=n) > 0).unsqueeze(1)
+            mn, mx = torch.where(has, mn, torch.zeros_like(mn)), torch.where(has, mx, torch.zeros_like(mx))
+            std = torch.sqrt(torch.relu(_scatter64(m * m, dst, n, "mean") - mean * mean) + 1e-5)
+            out = torch.cat([mean, mn, mx, std], -1)
+            out = torch.cat([out, out * (torch.log(deg + 1) / avg["log"]), out * (avg["log"] / torch.log(deg + 1))], -1)
+            outs.append(mlp(P, f"post_nns.{t}", torch.cat([xin, out], -1), cfg["post"]))
+        return torch.cat(outs, -1) @ P["lin.weight"].t() + P["lin.bias"]
+
+    _compare(layer, run_dev, run_ref, inputs, 1e-4)
+
+
 def test_a_two_layer_gnn_trains(conv):
     """OpProfiler.py:259-292 in miniature: CGConv -> relu -> SAGEConv -> mean readout, Adam, twenty steps on a fixed random
     graph: the loss falls, every parameter moves, nothing is NaN — and the weights the packed-operand cache hands out after
