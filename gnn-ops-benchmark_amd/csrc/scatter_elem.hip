@@ -320,7 +320,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
                                                                          T* __restrict__ out, int64_t* __restrict__ arg_out,
                                                                          int64_t B, int64_t E, int64_t K, int64_t N, int TC,
                                                                          int strips, int64_t rows, int nchunks,
-                                                                         int init_from_out, int tshift) {
+                                                                         int init_from_out, int tshift, int arg32) {
     static_assert(R == GNNOPS_MIN || R == GNNOPS_MAX, "min / max only");
     constexpr bool IS_MIN = R == GNNOPS_MIN;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -429,7 +429,10 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
                 if (r >= nloc) continue;
                 const int64_t o = (b * N + n_lo + r) * K + k0 + kk;
                 const int64_t e = winner(c[u]);
-                if (arg_out) arg_out[o] = e >= 0 ? e : E;
+                if (arg_out) {   // arg32: positions as int32 rows (E < 2^31), for a caller that widens them itself (ops.py dim-0 route)
+                    if (arg32) reinterpret_cast<int32_t*>(arg_out)[o] = (int32_t)(e >= 0 ? e : E);
+                    else arg_out[o] = e >= 0 ? e : E;
+                }
                 if (e >= 0) Elem<T>::store(out + o, val[u]);
                 else if (!init_from_out) Elem<T>::store(out + o, 0.f);  // torch_scatter: groups nothing reached become 0
             }
@@ -473,7 +476,7 @@ inline LdsGeom lds_geometry(int64_t N, int64_t K, int reduce, bool small_cell = 
 
 template <typename T, int R, typename I>
 int launch_lds(const T* src, const I* index, T* out, int64_t* arg_out, int64_t B, int64_t E, int64_t K, int64_t N,
-               LdsGeom g, int init_from_out, hipStream_t stream) {
+               LdsGeom g, int init_from_out, hipStream_t stream, int arg32 = 0) {
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_lds_kernel<T, R, I>),
@@ -503,7 +506,7 @@ int launch_lds(const T* src, const I* index, T* out, int64_t* arg_out, int64_t B
             const int th = lds_mm > 80 * 1024 ? LDS_THREADS : lds_mm > 40 * 1024 ? 512 : 256;
             hipLaunchKernelGGL((scatter_lds_minmax_kernel<T, R, CellT, I>), dim3((unsigned)(B * strips * g.nchunks)), dim3(th),
                                lds_mm, stream, src, index, out, arg_out, B, E, K, N, g.tc, strips, g.rows, g.nchunks,
-                               init_from_out, tshift);
+                               init_from_out, tshift, arg32);
             return gnnops_check_launch("scatter_lds");
         };
         if (small_cells(R, (int)sizeof(T), E)) return go(uint32_t{});
@@ -516,13 +519,13 @@ int launch_lds(const T* src, const I* index, T* out, int64_t* arg_out, int64_t B
 
 template <typename T, typename I>
 int dispatch_lds(int reduce, const T* src, const I* index, T* out, int64_t* arg_out, int64_t B, int64_t E,
-                 int64_t K, int64_t N, LdsGeom g, int init_from_out, hipStream_t stream) {
+                 int64_t K, int64_t N, LdsGeom g, int init_from_out, hipStream_t stream, int arg32 = 0) {
     switch (reduce) {
         case GNNOPS_SUM: return launch_lds<T, GNNOPS_SUM, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
         case GNNOPS_MEAN: return launch_lds<T, GNNOPS_MEAN, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
         case GNNOPS_MUL: return launch_lds<T, GNNOPS_MUL, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
-        case GNNOPS_MIN: return launch_lds<T, GNNOPS_MIN, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
-        case GNNOPS_MAX: return launch_lds<T, GNNOPS_MAX, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+        case GNNOPS_MIN: return launch_lds<T, GNNOPS_MIN, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream, arg32);
+        case GNNOPS_MAX: return launch_lds<T, GNNOPS_MAX, I>(src, index, out, arg_out, B, E, K, N, g, init_from_out, stream, arg32);
     }
     return GNNOPS_EINVAL;
 }
@@ -532,7 +535,7 @@ inline int grid_for(int64_t n) { return gnnops_grid_cap(gnnops_cdiv(n, 256), 256
 
 template <typename T>
 int run(const void* src_, const void* index_, int index_bytes, void* out_, int64_t* arg_out, int64_t B, int64_t E, int64_t K,
-        int64_t N, int reduce, int init_from_out, void* workspace, hipStream_t stream) {
+        int64_t N, int reduce, int init_from_out, void* workspace, hipStream_t stream, int arg32 = 0) {
     const int64_t* index = (const int64_t*)index_;   // the memory-side-atomic fallback below takes the int64 index only
     const T* src = (const T*)src_;
     T* out = (T*)out_;
@@ -544,13 +547,13 @@ int run(const void* src_, const void* index_, int index_bytes, void* out_, int64
     if (const LdsGeom g = lds_geometry(N, K, reduce, small_cells(reduce, (int)sizeof(T), E), B);
         g.tc > 0 && B * gnnops_cdiv(K, g.tc) * g.nchunks < ((int64_t)1 << 31) && E < ((int64_t)1 << 31)) {
         if (index_bytes == 4)
-            return dispatch_lds<T, int32_t>(reduce, src, (const int32_t*)index_, out, arg_out, B, E, K, N, g, init_from_out, stream);
+            return dispatch_lds<T, int32_t>(reduce, src, (const int32_t*)index_, out, arg_out, B, E, K, N, g, init_from_out, stream, arg32);
         if (index_bytes == 2)
-            return dispatch_lds<T, uint16_t>(reduce, src, (const uint16_t*)index_, out, arg_out, B, E, K, N, g, init_from_out, stream);
-        return dispatch_lds<T, int64_t>(reduce, src, index, out, arg_out, B, E, K, N, g, init_from_out, stream);
+            return dispatch_lds<T, uint16_t>(reduce, src, (const uint16_t*)index_, out, arg_out, B, E, K, N, g, init_from_out, stream, arg32);
+        return dispatch_lds<T, int64_t>(reduce, src, index, out, arg_out, B, E, K, N, g, init_from_out, stream, arg32);
     }
-    if (index_bytes != 8) {
-        gnnops_set_error("scatter_elementwise: a narrowed index is taken by the LDS-strip form only (B=%lld N=%lld K=%lld)",
+    if (index_bytes != 8 || arg32) {
+        gnnops_set_error("scatter_elementwise: a narrowed index / int32 arg is taken by the LDS-strip form only (B=%lld N=%lld K=%lld)",
                          (long long)B, (long long)N, (long long)K);
         return GNNOPS_EUNSUPPORTED;
     }
@@ -636,6 +639,19 @@ extern "C" int gnnops_scatter_elementwise_ix(const void* src, const void* index,
                                              int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce,
                                              int init_from_out, void* workspace, size_t workspace_bytes,
                                              gnnops_stream_t s) {
+    return gnnops_scatter_elementwise_ixa(src, index, index_bytes, out, arg_out, 8, B, E, K, N, dtype, reduce, init_from_out, workspace,
+                                          workspace_bytes, s);
+}
+
+// The same with the arg rows stored in `arg_bytes` bytes per element: 8 (int64, what torch_scatter returns) or 4 (int32; min / max,
+// E < 2^31, the LDS-strip form only — GNNOPS_EUNSUPPORTED otherwise) for a caller that widens them itself on a later pass.
+extern "C" int gnnops_scatter_elementwise_ixa(const void* src, const void* index, int index_bytes, void* out, void* arg_out_,
+                                              int arg_bytes, int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce,
+                                              int init_from_out, void* workspace, size_t workspace_bytes, gnnops_stream_t s) {
+    int64_t* arg_out = (int64_t*)arg_out_;
+    const int arg32 = arg_bytes == 4 ? 1 : 0;
+    GNNOPS_REQUIRE(arg_bytes == 8 || (arg_bytes == 4 && (reduce == GNNOPS_MIN || reduce == GNNOPS_MAX) && E < ((int64_t)1 << 31)),
+                   GNNOPS_EINVAL, "scatter_elementwise: arg_bytes %d", arg_bytes);
     hipStream_t stream = (hipStream_t)s;
     GNNOPS_REQUIRE(B >= 0 && E >= 0 && K >= 0 && N >= 0, GNNOPS_EINVAL, "scatter_elementwise: negative size");
     GNNOPS_REQUIRE(reduce >= GNNOPS_SUM && reduce <= GNNOPS_MUL, GNNOPS_EINVAL, "scatter_elementwise: reduce %d", reduce);
@@ -651,9 +667,9 @@ extern "C" int gnnops_scatter_elementwise_ix(const void* src, const void* index,
     GNNOPS_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), GNNOPS_EWORKSPACE,
                    "scatter_elementwise: workspace %zu < %zu", workspace_bytes, need);
     switch (dtype) {
-        case GNNOPS_F32: return run<float>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
-        case GNNOPS_F16: return run<__half>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
-        case GNNOPS_BF16: return run<__hip_bfloat16>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream);
+        case GNNOPS_F32: return run<float>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream, arg32);
+        case GNNOPS_F16: return run<__half>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream, arg32);
+        case GNNOPS_BF16: return run<__hip_bfloat16>(src, index, index_bytes, out, arg_out, B, E, K, N, reduce, init_from_out, workspace, stream, arg32);
     }
     gnnops_set_error("scatter_elementwise: unknown dtype %d", dtype);
     return GNNOPS_EINVAL;

@@ -129,10 +129,12 @@ __global__ void reduce_runs_kernel(const T* __restrict__ value, const uint32_t* 
 }
 
 // ---- dense 2-D transpose through a padded LDS tile (64 x 64 elements, conflict-free column reads) ----
-template <typename U>
-__global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in, U* __restrict__ out, int64_t R,
+// O != U: the elements are converted on the way (int64 -> int32 index narrowing / int32 -> int64 arg widening of the
+// dim-0 route of large full-index scatters, ops.py: the tile holds the OUTPUT type).
+template <typename U, typename O = U>
+__global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in, O* __restrict__ out, int64_t R,
                                                         int64_t C) {
-    __shared__ U tile[64][64 + (sizeof(U) >= 4 ? 1 : 4 / sizeof(U))];
+    __shared__ O tile[64][64 + (sizeof(O) >= 4 ? 1 : 4 / sizeof(O))];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     in += (int64_t)blockIdx.z * R * C;   // batch of independent [R, C] matrices
     out += (int64_t)blockIdx.z * R * C;
@@ -142,12 +144,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = in[(r0 + ty + 4 * j) * C + c0 + tx];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) tile[ty + 4 * j][tx] = v[j];
+        for (int j = 0; j < 16; ++j) tile[ty + 4 * j][tx] = (O)v[j];
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int64_t r = r0 + ty + 4 * j, c = c0 + tx;
-            if (r < R && c < C) tile[ty + 4 * j][tx] = in[r * C + c];
+            if (r < R && c < C) tile[ty + 4 * j][tx] = (O)in[r * C + c];
         }
     }
     __syncthreads();
@@ -289,6 +291,20 @@ extern "C" int gnnops_coalesce(const int64_t* row, const int64_t* col, const voi
 
 extern "C" int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes, gnnops_stream_t s) {
     return gnnops_transpose_batched(in, out, 1, R, C, elem_bytes, s);
+}
+
+// [R, C] int64 -> [C, R] int32 (mode 0: every value must fit) or [R, C] int32 -> [C, R] int64 (mode 1, sign-extended).
+extern "C" int gnnops_transpose2d_cvt(const void* in, void* out, int64_t R, int64_t C, int mode, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(R >= 0 && C >= 0 && (mode == 0 || mode == 1), GNNOPS_EINVAL, "transpose2d_cvt: bad argument");
+    if (R * C == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(in && out, GNNOPS_EINVAL, "transpose2d_cvt: null pointer");
+    GNNOPS_REQUIRE(gnnops_cdiv(R, 64) < 65536, GNNOPS_EUNSUPPORTED, "transpose2d_cvt: too many rows");
+    dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64), 1);
+    if (mode == 0)
+        hipLaunchKernelGGL((transpose_kernel<int64_t, int32_t>), grid, dim3(256), 0, (hipStream_t)s, (const int64_t*)in, (int32_t*)out, R, C);
+    else
+        hipLaunchKernelGGL((transpose_kernel<int32_t, int64_t>), grid, dim3(256), 0, (hipStream_t)s, (const int32_t*)in, (int64_t*)out, R, C);
+    return gnnops_check_launch("transpose2d_cvt");
 }
 
 extern "C" int gnnops_transpose_batched(const void* in, void* out, int64_t batch, int64_t R, int64_t C, int elem_bytes,

@@ -322,6 +322,42 @@ def _broadcast_index(index, src, dim):
     return index.expand(src.shape)
 
 
+def _scatter_transposed(src2, full, N, reduce, rcode, dt, L):
+    """The dim-0 route of a large full-index scatter (src2, full: [E, K]; N destinations per column; the reference's
+    (38000, 38000) shapes): reduce along the LAST dim of the transposed operands, where the element kernel streams whole rows.
+    Of the 69 GB that route moved in transposes at (38000)^2, 46 were the int64 index going in and the int64 arg coming out:
+    the index is narrowed to int32 INSIDE its transpose and the positions come out of the kernel as int32 rows, widened inside
+    the transpose back (gnnops_transpose2d_cvt, gnnops_scatter_elementwise_ixa). Returns out [N, K] (and arg), or None when
+    the kernel does not take the narrowed operands (the caller then takes the int64 route)."""
+    from .sparse import transpose_contiguous
+
+    E, K = src2.shape
+    if E >= 2 ** 31 or N >= 2 ** 31:
+        return None
+    dev = src2.device
+    want_arg = rcode in (_lib.MIN, _lib.MAX)
+    src_t = transpose_contiguous(src2)                                          # [K, E]
+    idx_t = torch.empty((K, E), dtype=torch.int32, device=dev)
+    out_t = torch.empty((K, N), dtype=src2.dtype, device=dev)
+    arg_t = torch.empty((K, N), dtype=torch.int32, device=dev) if want_arg else None
+    ws_bytes = L.gnnops_scatter_elementwise_workspace_bytes(K, N, 1, dt, rcode)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    with _on(dev):
+        check(L.gnnops_transpose2d_cvt(full.data_ptr(), idx_t.data_ptr(), E, K, 0, _stream()), "transpose2d_cvt")
+        rc = L.gnnops_scatter_elementwise_ixa(src_t.data_ptr(), idx_t.data_ptr(), 4, out_t.data_ptr(),
+                                              arg_t.data_ptr() if want_arg else None, 4 if want_arg else 8, K, E, 1, N, dt, rcode, 0,
+                                              ws.data_ptr(), ws_bytes, _stream())
+        if rc == _lib.EUNSUPPORTED:
+            return None
+        check(rc, "scatter_elementwise")
+        out = transpose_contiguous(out_t)                                       # [N, K]
+        if not want_arg:
+            return out
+        arg = torch.empty((N, K), dtype=torch.int64, device=dev)
+        check(L.gnnops_transpose2d_cvt(arg_t.data_ptr(), arg.data_ptr(), K, N, 1, _stream()), "transpose2d_cvt")
+    return out, arg
+
+
 def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
     """torch_scatter.scatter(src, index, dim, out, dim_size, reduce). min/max return (out, arg_out)."""
     if reduce not in REDUCE_CODE:
@@ -382,10 +418,13 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
                 shape = list(src.shape)
                 shape[dim] = N
                 full = _broadcast_index(index, src, dim).contiguous().view(E, K)      # B == 1: [E, K] around `dim`
-                res = scatter(transpose_contiguous(src.view(E, K)), transpose_contiguous(full), 1, None, N, reduce)
+                res = _scatter_transposed(src.view(E, K), full, N, reduce, rcode, dt, L)
+                if res is None:      # the element kernel does not take the narrowed operands at this shape: int64 all the way
+                    res = scatter(transpose_contiguous(src.view(E, K)), transpose_contiguous(full), 1, None, N, reduce)
+                    res = tuple(transpose_contiguous(r) for r in res) if isinstance(res, tuple) else transpose_contiguous(res)
                 if isinstance(res, tuple):
-                    return transpose_contiguous(res[0]).view(shape), transpose_contiguous(res[1]).view(shape)
-                return transpose_contiguous(res).view(shape)
+                    return res[0].view(shape), res[1].view(shape)
+                return res.view(shape)
         shape = list(src.shape)
         shape[dim] = N
         out = torch.empty(shape, dtype=src.dtype, device=src.device)

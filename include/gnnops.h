@@ -180,6 +180,13 @@ int gnnops_scatter_elementwise(const void* src, const int64_t* index, void* out,
 int gnnops_scatter_elementwise_ix(const void* src, const void* index, int index_bytes, void* out, int64_t* arg_out,
                                   int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
                                   void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
+/* The same with the arg rows of min / max stored as int32 (arg_bytes 4; E < 2^31; the LDS-strip form only, GNNOPS_EUNSUPPORTED
+ * otherwise) or int64 (arg_bytes 8 = gnnops_scatter_elementwise_ix): the dim-0 route of large full-index scatters
+ * (data/scatter_max.csv:32-33, (38000, 38000)) reduces along the last dim of TRANSPOSED operands and widens the positions inside
+ * the transpose back (gnnops_transpose2d_cvt), so neither the int64 index nor an int64 arg crosses a transpose. */
+int gnnops_scatter_elementwise_ixa(const void* src, const void* index, int index_bytes, void* out, void* arg_out, int arg_bytes,
+                                   int64_t B, int64_t E, int64_t K, int64_t N, int dtype, int reduce, int init_from_out,
+                                   void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
 /* out[i] = (int32 / uint16) index[i], i < n, for ids in [0, bound); an id outside becomes all ones (-1 / 0xFFFF — never a valid
  * id: bound <= 65535 for out_bytes 2, < 2^31 for 4), which the element kernels drop as they drop it in the int64 index. */
 int gnnops_narrow_index(const int64_t* index, void* out, int64_t n, int out_bytes, int64_t bound, gnnops_stream_t stream);
@@ -293,6 +300,8 @@ int gnnops_coalesce(const int64_t* row, const int64_t* col, const void* value, i
  * in [R, C] -> out [C, R]; elem_bytes in {1, 2, 4, 8}; bit-exact. */
 int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem_bytes,
                        gnnops_stream_t stream);
+/* [R, C] int64 -> [C, R] int32 (mode 0: every value must fit in 31 bits) or [R, C] int32 -> [C, R] int64 (mode 1). */
+int gnnops_transpose2d_cvt(const void* in, void* out, int64_t R, int64_t C, int mode, gnnops_stream_t stream);
 /* batch of independent [R, C] -> [C, R] copies (in / out [batch, R, C] / [batch, C, R]). */
 int gnnops_transpose_batched(const void* in, void* out, int64_t batch, int64_t R, int64_t C, int elem_bytes,
                              gnnops_stream_t stream);

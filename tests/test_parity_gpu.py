@@ -524,7 +524,7 @@ def test_csr_cache_hits_for_the_same_coo_tensor(gnnops):
 
 
 @pytest.mark.parametrize("dname,reduce", [("f32", "max"), ("f32", "min"), ("f32", "mean"), ("f32", "sum"), ("f16", "sum"), ("f32", "mul")])
-def test_layout_f_dim0_more_destinations_than_an_lds_strip(gnnops, oracle, reduce, dname):
+def test_layout_f_dim0_more_destinations_than_an_lds_strip(gnnops, oracle, reduce, dname, monkeypatch):
     """Full-shape index along dim 0 with N too large for an LDS strip of destinations (the reference's (38000, 38000) shapes,
     data/scatter_max.csv:32-33): routed through tile transposes + the last-dim kernel. Values and arg bit-exact for min / max,
     sums / means / products within the layout-F tolerance; also a 3-D src reduced along dim 0."""
@@ -534,7 +534,13 @@ def test_layout_f_dim0_more_destinations_than_an_lds_strip(gnnops, oracle, reduc
     src = (torch.rand(E, K, generator=g) * 2 - 1).to(TORCH_DT[dname])
     idx = torch.randint(0, N, (E, K), generator=g)
     idx[:40] = idx[40:80]                                        # ties for min / max, repeated destinations for sums
+    from gnnops import ops
+
+    took = []
+    real = ops._scatter_transposed
+    monkeypatch.setattr(ops, "_scatter_transposed", lambda *a: (lambda r: (took.append(r is not None), r)[1])(real(*a)))
     got = gnnops.scatter(src.cuda(), idx.cuda(), 0, dim_size=N, reduce=reduce)
+    assert took == [True], "the narrowed route (int32 index / arg inside the transposes) did not take the call"
     exp = oracle.scatter(to_np(src), idx.numpy(), dim=0, dim_size=N, reduce=reduce, dtype=dname)
     if reduce in ("min", "max"):
         assert_bits_equal(to_np(got[0]), exp[0], reduce)
