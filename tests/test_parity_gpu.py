@@ -555,6 +555,35 @@ def test_layout_f_dim0_more_destinations_than_an_lds_strip(gnnops, oracle, reduc
     _close(to_np(g3).reshape(N, K), e3, dname, 4, reduce + " 3-D")
 
 
+def test_implicit_dim_size_is_remembered_per_index_tensor(gnnops, oracle, monkeypatch):
+    """torch_scatter's dim_size=None means int(index.max()) + 1: a full read of the index and a host round trip per call. With
+    the plan cache on it is remembered per index tensor object + version (an in-place write recomputes it); with the cache off
+    — the cold numbers — it is computed on every call."""
+    from gnnops import ops
+
+    calls = []
+    real = ops._index_max_now
+    monkeypatch.setattr(ops, "_index_max_now", lambda i: (calls.append(1), real(i))[1])
+    g = torch.Generator().manual_seed(31)
+    src = torch.rand(400, 32, generator=g)
+    idx = torch.randint(0, 90, (400, 32), generator=g)
+    d_src, d_idx = src.cuda(), idx.cuda()
+    gnnops.set_plan_cache(True)
+    try:
+        for _ in range(3):
+            out = gnnops.scatter_add(d_src, d_idx, 0)
+        assert len(calls) == 1 and out.shape == (int(idx.max()) + 1, 32)
+        d_idx[0, 0] = 200                                   # in-place write: new version, new maximum
+        out = gnnops.scatter_add(d_src, d_idx, 0)
+        assert len(calls) == 2 and out.shape == (201, 32)
+        gnnops.set_plan_cache(False)
+        for _ in range(2):
+            gnnops.scatter_add(d_src, d_idx, 0)
+        assert len(calls) == 4
+    finally:
+        gnnops.set_plan_cache(False)
+
+
 @pytest.mark.parametrize("N,dname", [(700, "f16"), (700, "f32"), (70_000, "f32"), (65536, "bf16"), (65537, "f16")])
 @pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max", "mul"])
 def test_layout_f_narrowed_index_copies(gnnops, oracle, reduce, N, dname):
