@@ -736,6 +736,360 @@ int launch_dma256(const void* input, const void* mat1, const void* mat2, void* o
     return launch_dma256_var<T, IS_BF16, 2>(input, mat1, mat2, out, M, N, K, lda, ldb, ldadd, stream);
 }
 
+// ---- split-K tail over the same 256 x 256 tiles: ONE persistent workgroup per CU --------------------------------------
+// A grid of T tiles on G CUs runs in ceil(T / G) rounds whatever T is: the reference's sweep (benchmark_native_addmm.py:23-27,
+// L = 1581 ... 8164, whatever int(sqrt(x)) gives) makes 17 x 17 = 289 tiles cost what 19 x 19 = 361 cost (two rounds, the
+// second with 33 tiles: measured 248.6 against 244.8 us). Here the whole rounds run as before (workgroup v takes tiles v,
+// v + G, ... — every workgroup of an XCD at the same K-step of neighbouring tiles, which is what lets one L2 serve 12
+// operand panels to 32 tiles), and the r = T mod G tiles of the last round are cut along K into s = 8, 4 or 2 pieces
+// (r <= 32, 64, 128), one workgroup each. Classic stream-K (one sequence of K-steps cut into G equal ranges) was built
+// first and measured: ranges start at arbitrary K offsets, no two workgroups of an XCD read the same panel rows at the
+// same time, every operand byte crosses the fabric once per tile and the main loop runs at HALF speed
+// (profiles/round3_f_gemm_streamk.txt) — the pieces must be in phase. So: XCD x multiplies piece x mod s of the tail tiles
+// (8 / s interleaved subsets of them): all its workgroups walk the same K range of neighbouring tiles.
+// The s workgroups of a tile are s CONSECUTIVE block ids (they sit on s different XCDs). Each leaves its fp32
+// accumulators in its own 256 KiB slot of the workspace (register order: 32 x 16 B per lane, coalesced), raises its
+// flag, waits for its s - 1 partners' flags and finishes 1 / s of the tile: the 16-row blocks [j 8 / s, (j + 1) 8 / s) of
+// every wave — its own registers plus that part of the partners' slots — through the ordinary epilogue. Every workgroup
+// has written everything others wait for BEFORE it waits itself, and a tile's workgroups are adjacent in dispatch order:
+// with in-order dispatch any eight free CUs are enough for progress, whatever else is running on the chip.
+// Hand-off as MI355X_MICROARCH.md "Valid forms" prescribes: plain stores, every wave's vmcnt(0), workgroup barrier, lane 0
+// agent release + vmcnt(0) + relaxed agent flag store | relaxed polls, one agent acquire, vmcnt(0), barrier, plain loads.
+// Tile ids run down bands of eight tile-rows (column after column inside a band) and, in the whole rounds, workgroup
+// v = the v-th of its XCD's contiguous share: the 32 workgroups of an XCD sit on an 8 x 4 block of tiles.
+constexpr int SK_SLOT_FLOATS = BM2 * BN2;  // 256 KiB of fp32 per workgroup
+constexpr unsigned SK_SPIN_LIMIT = 1u << 25;  // polls of ~0.1 us each before an owner gives up and poisons its tile
+
+__device__ inline void sk_tile_rc(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int band = id / (8 * tiles_n);
+    const int rows = (tiles_m - band * 8 < 8) ? tiles_m - band * 8 : 8;
+    const int local = id - band * 8 * tiles_n;
+    tn = local / rows;
+    tm = band * 8 + local % rows;
+}
+
+template <typename T, bool IS_BF16>
+__global__ __launch_bounds__(512, 2) void gemm_sk256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
+                                                            const T* __restrict__ addend, T* __restrict__ C, int64_t M,
+                                                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd,
+                                                            float* __restrict__ slots, unsigned* __restrict__ flags,
+                                                            int tiles_m, int tiles_n, int dp_tiles, int tail_tiles, int split, int order) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
+    unsigned char* smem = smem256;
+    __shared__ int poisoned;
+
+    const int G = (int)gridDim.x;
+    const int v = ((order & 1) && (G & 7) == 0) ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int64_t S = K / BK4;
+    int dp_next = v;
+    // tail: block b = 8 i + x (XCD x): piece x mod split of tail tile i (8 / split) + x / split
+    const int tail_j = (int)blockIdx.x & (split - 1);
+    const int tail_t = ((int)blockIdx.x >> 3) * (8 / split) + (((int)blockIdx.x & 7) / split);
+    bool tail_left = split > 1 && tail_t < tail_tiles && !(order & 8);   // order bits 4, 8: timing-only builds of the A/B tool
+    if (threadIdx.x == 0) poisoned = 0;
+    const bool vec_c = (N % 8 == 0) && ((uintptr_t)C % 16 == 0) && (addend == nullptr || (uintptr_t)addend % 16 == 0);
+    const bool half_c = (N % 4 == 0) && ((uintptr_t)C % 8 == 0) && (addend == nullptr || (uintptr_t)addend % 8 == 0);
+
+    for (;;) {
+        int t;
+        int64_t kb, ke;
+        bool is_tail = false;
+        if (dp_next < dp_tiles) {
+            t = dp_next;
+            dp_next += G;
+            kb = 0;
+            ke = S;
+        } else if (tail_left) {
+            tail_left = false;
+            is_tail = true;
+            t = dp_tiles + tail_t;
+            kb = S * tail_j / split;
+            ke = S * (tail_j + 1) / split;
+        } else {
+            break;
+        }
+        int tm, tn;
+        if (order & 2) sk_tile_rc(t, tiles_m, tiles_n, tm, tn);
+        else { tm = t / tiles_n; tn = t - tm * tiles_n; }
+        const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+        const int64_t ksteps = ke - kb;
+        // per-lane constants are rebuilt for every piece from a value the compiler cannot see through: hoisted out of the
+        // persistent loop they (and the epilogue's addresses) stay live across the main loop and spill
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wr = wave >> 2, wc = wave & 3;
+        const int a_row = wr * 128 + (lane & 15);
+        const int a_kc = lane >> 4;
+        const int b_q = (lane & 15) >> 2, b_p = lane & 3;
+        const int b_row = 8 * (lane >> 4) + b_q;
+        const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem;
+        const uint32_t a_rd = smem_lds + a4_off(a_row, a_kc);
+        const uint32_t b_rd = smem_lds + A2_BYTES + (wc >> 1) * (B2_BYTES / 2);
+        uint32_t b_lo_off[4], b_hi_off[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int ch = (wc & 1) * 8 + ni * 2 + (b_p >> 1);
+            b_lo_off[ni] = b_rd + b_off(b_row, ch) + 8 * (b_p & 1);
+            b_hi_off[ni] = b_rd + b_off(b_row + 4, ch) + 8 * (b_p & 1);
+        }
+
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const uint16_t* a_src[2];
+        const uint16_t* b_src[2];
+        int b_dst[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ar = (wave * 2 + p) * 16 + (lane >> 2);
+            const int64_t arow = (m0 + ar < M) ? m0 + ar : M - 1;
+            a_src[p] = A + arow * lda + kb * BK4 + (((lane & 3) ^ a4_swz(ar)) << 3);
+            const int q = wave * 2 + p, half = q >> 3;
+            const int br = (q & 7) * 4 + (lane >> 4);
+            int64_t bcol = n0 + half * 128 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
+            if (bcol > ldb - 8) bcol = ldb - 8;
+            b_src[p] = Bm + (kb * BK4 + br) * ldb + bcol;
+            b_dst[p] = A2_BYTES + half * (B2_BYTES / 2) + (q & 7) * 1024;
+        }
+        auto dma_tile = [&](int64_t tn_) {
+            const int stage = (int)(tn_ & (NST - 1));
+            const int64_t k0 = (tn_ < ksteps ? tn_ : ksteps - 1) * BK4;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + stage * STAGE2_BYTES + (wave * 2 + p) * 1024),
+                                                 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
+                                                 (__attribute__((address_space(3))) void*)(smem + stage * STAGE2_BYTES + b_dst[p]), 16, 0, 0);
+            }
+        };
+        s16x8 af[8];
+        s16x4 blo[4], bhi[4];
+        auto read_all = [&](int64_t tt) {
+            const uint32_t st = (uint32_t)(tt & (NST - 1)) * STAGE2_BYTES;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[ni]) : "v"(b_lo_off[ni] + st));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bhi[ni]) : "v"(b_hi_off[ni] + st));
+            }
+            const uint32_t aa = a_rd + st;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(af[1]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[2]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(af[3]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[4]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(af[5]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(af[6]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(af[7]) : "v"(aa));
+        };
+        auto wait_reads = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]),
+                           "+v"(bhi[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                           "+v"(af[6]), "+v"(af[7]));
+        };
+        auto compute = [&]() {
+            s16x8 bf[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                bf[ni] = s16x8{blo[ni].x, blo[ni].y, blo[ni].z, blo[ni].w, bhi[ni].x, bhi[ni].y, bhi[ni].z, bhi[ni].w};
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16<IS_BF16>(af[mi], bf[ni], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // the ping-pong main loop of gemm_dma256_kernel (VAR 2), over K-steps kb .. ke-1 of this tile
+        dma_tile(0);
+        dma_tile(1);
+        dma_tile(2);
+        if (__builtin_amdgcn_readfirstlane(wave) < 4) {
+            dma_tile(3);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            read_all(0);
+            for (int64_t kt = 0; kt < ksteps; ++kt) {
+                wait_reads();
+                compute();
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                read_all(kt + 1);
+                dma_tile(kt + 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int64_t kt = 0; kt < ksteps; ++kt) {
+                read_all(kt);
+                dma_tile(kt + 3);
+                wait_reads();
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                compute();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]),
+                       "+v"(bhi[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                       "+v"(af[6]), "+v"(af[7])
+                     :
+                     : "memory");
+        __syncthreads();  // every DMA landed, every fragment read: the stages are free (epilogue staging, next piece)
+
+        int mi_lo = 0, mi_hi = 8;   // the 16-row blocks of every wave's 128 rows this workgroup stores
+        if (is_tail && !(order & 4)) {
+            const int b0 = (int)blockIdx.x - tail_j;   // the tile's workgroups: blocks b0 .. b0 + split - 1
+            mi_lo = tail_j * (8 / split);
+            mi_hi = mi_lo + 8 / split;
+            f32x4* slot = reinterpret_cast<f32x4*>(slots + (size_t)blockIdx.x * SK_SLOT_FLOATS) + tid;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < mi_lo || i >= mi_hi) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) slot[(i * 4 + j) * 512] = acc[i][j];
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int p = 0; p < split; ++p) {
+                    if (p == tail_j) continue;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(flags + b0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > SK_SPIN_LIMIT) {
+                            poisoned = 1;
+                            break;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            for (int p = 0; p < split; ++p) {
+                if (p == tail_j) continue;
+                const f32x4* ps = reinterpret_cast<const f32x4*>(slots + (size_t)(b0 + p) * SK_SLOT_FLOATS) + tid;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i >= mi_lo && i < mi_hi) {
+                        f32x4 part[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) part[j] = ps[(i * 4 + j) * 512];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] += part[j];
+                    }
+            }
+            if (poisoned) {   // a partner never showed up: make the failure visible in the output instead of hanging
+                const float bad = __builtin_nanf("");
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bad, bad, bad, bad};
+            }
+        }
+        // the epilogue of gemm_dma256_kernel
+        const int pr = lane >> 3, pc = (lane & 7) * 8;
+        float* ctile = reinterpret_cast<float*>(smem) + wave * (EPI2_ROWS * CS);
+        const bool pre_ok = vec_c && addend != nullptr && m0 + BM2 <= M && n0 + BN2 <= N;
+        u32x4 pre[16];
+        if (pre_ok) {
+            const T* ap = addend + (m0 + wr * 128 + pr) * ldadd + n0 + wc * 64 + pc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const u32x4*>(ap + (int64_t)i * 8 * ldadd);
+        }
+#pragma unroll
+        for (int c = 0; c < 128 / EPI2_ROWS; ++c) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ctile[(h * 16 + (lane >> 4) * 4 + r) * CS + ni * 16 + (lane & 15)] = acc[c * 2 + h][ni][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int pass = 0; pass < EPI2_ROWS / 8; ++pass) {
+                if (c * 2 + pass / 2 < mi_lo || c * 2 + pass / 2 >= mi_hi) continue;
+                const int rr = pass * 8 + pr;
+                float f[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(&ctile[rr * CS + pc + 4]);
+                f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+                const int64_t row = m0 + wr * 128 + c * EPI2_ROWS + rr, col = n0 + wc * 64 + pc;
+                if (pre_ok) {
+                    float g[8];
+                    Elem<T>::unpack(pre[c * 4 + pass], g);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] += g[i];
+                    *reinterpret_cast<u32x4*>(C + row * N + col) = Elem<T>::pack(f);
+                } else {
+                    epi_store8<T>(C, addend, row, col, M, N, f, vec_c, half_c, ldadd);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();  // the staging rows of every wave are read: the next piece's DMA may overwrite them
+    }
+}
+
+inline int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n = v;
+    }
+    return n;
+}
+
+// The K split of the last round's tiles (1: plain grid launch — whole rounds already, more than half a round left, or off).
+inline int sk_split_of(int64_t T, int G) {
+    const char* sw = getenv("GNNOPS_GEMM_SK");  // A/B (tools/time_gemm_sk.py): 0 = off, 3 = persistent loop for whole rounds too
+    if (sw && sw[0] == '0') return 1;
+    if ((G & 7) != 0 || T < G) return 1;
+    const int64_t r = T % G;
+    if (r == 0) return (sw && sw[0] == '3') ? 8 : 1;
+    const int per_xcd = G / 8;   // tail tiles one XCD can take per piece
+    if (r <= per_xcd) return 8;
+    if (r <= 2 * per_xcd) return 4;
+    if (r <= 4 * per_xcd) return 2;
+    return 1;
+}
+inline size_t sk_flag_bytes(int G) { return ((size_t)G * 4 + 1023) / 1024 * 1024; }
+inline size_t sk_workspace_bytes(int G) { return (size_t)G * SK_SLOT_FLOATS * 4 + sk_flag_bytes(G); }
+
+template <typename T, bool IS_BF16>
+int launch_sk256(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K, int64_t lda,
+                 int64_t ldb, int64_t ldadd, void* sk_ws, int split, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk256_kernel<T, IS_BF16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_SMEM) != hipSuccess)
+            return gnnops_check_launch("addmm attribute");
+        configured = true;
+    }
+    const int G = cu_count();
+    unsigned* flags = reinterpret_cast<unsigned*>((char*)sk_ws + (size_t)G * SK_SLOT_FLOATS * 4);
+    if (hipMemsetAsync(flags, 0, sk_flag_bytes(G), stream) != hipSuccess) return gnnops_check_launch("addmm flags");
+    const int tiles_m = (int)gnnops_cdiv(M, BM2), tiles_n = (int)gnnops_cdiv(N, BN2);
+    const char* od = getenv("GNNOPS_GEMM_SK_ORDER");  // A/B: bit 0 = workgroup id by XCD share, bit 1 = tile ids down bands of 8 rows
+    const int order = od ? atoi(od) : 3;
+    const int tail_tiles = (int)((int64_t)tiles_m * tiles_n % G), dp_tiles = tiles_m * tiles_n - tail_tiles;
+    hipLaunchKernelGGL((gemm_sk256_kernel<T, IS_BF16>), dim3((unsigned)G), dim3(512), GEMM256_SMEM, stream, (const uint16_t*)mat1,
+                       (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K, lda, ldb, ldadd, (float*)sk_ws, flags, tiles_m,
+                       tiles_n, dp_tiles, tail_tiles, split, order);
+    return gnnops_check_launch("addmm stream-K");
+}
+
 // ---- fp32 operands: v_mfma_f32_16x16x4_f32 (exact fp32 products and sums, 1/16 of the bf16 MFMA rate = the fp32
 // vector peak, MI355X_MICROARCH.md "Matrix cores"). Same 128 x 128 block / 2 x 2 waves / 4 x 4 MFMA tiles; BK = 16.
 // A tile [128][16] with 20-float rows and B tile [16][128] with 144-float rows: both fragment reads (one ds_read_b32
@@ -1270,22 +1624,58 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_w4_kernel(const float* __rest
     }
 }
 
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int ALIGN>
 __global__ void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t cols,
                                 int64_t ld, int64_t rows_out) {
     const int64_t chunks = ld / 8, total = rows_out * chunks;  // one 16-B output chunk per thread; rows >= `rows` are zero
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // each workgroup writes ONE contiguous span (DESIGN.md "store shape": grid-strided 16-B stores run 10-25 % below this)
+    const int64_t span = (total + gridDim.x - 1) / gridDim.x;
+    const int64_t i_end = ((int64_t)blockIdx.x + 1) * span < total ? ((int64_t)blockIdx.x + 1) * span : total;
+    for (int64_t i = (int64_t)blockIdx.x * span + threadIdx.x; i < i_end; i += blockDim.x) {
         const int64_t r = i / chunks, c = (i % chunks) * 8;
         u32x4 v;
         if constexpr (ALIGN >= 4) {
             v = load8<ALIGN>(in, r, c, rows, cols);
         } else {
-            const uint16_t* p = in + r * cols + c;
-            uint16_t e[8];
+            // rows of odd length (the reference's L = int(sqrt(x))): every other row starts 2 bytes off a dword. Whole
+            // dwords are read from the dword at or below the piece and shifted by 0 or 2 bytes — five loads (one dwordx4 +
+            // one dword) instead of eight 2-byte ones; a dword is read only if it holds a valid element, so nothing past
+            // the last row is touched, and elements past the row end are cleared after the shift.
+            v = u32x4{0u, 0u, 0u, 0u};
+            if (r < rows && c < cols) {
+                const int64_t left = cols - c;
+                const int n = left < 8 ? (int)left : 8;
+                const uint16_t* p = in + r * cols + c;
+                const int odd = (int)((reinterpret_cast<uintptr_t>(p) >> 1) & 1);
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(p - odd);
+                const int nd = (odd + n + 1) >> 1;   // dwords holding elements odd .. odd + n - 1
+                uint32_t d[5] = {0u, 0u, 0u, 0u, 0u};
+                if (nd >= 4) {
+                    const u32x4_a4 w = *reinterpret_cast<const u32x4_a4*>(q);
+                    d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+                    if (nd == 5) d[4] = q[4];
+                } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = (r < rows && c + j < cols) ? p[j] : (uint16_t)0;
-            v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
-            v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+                    for (int j = 0; j < 3; ++j)
+                        if (j < nd) d[j] = q[j];
+                }
+                if (odd) {
+                    v.x = (d[0] >> 16) | (d[1] << 16); v.y = (d[1] >> 16) | (d[2] << 16);
+                    v.z = (d[2] >> 16) | (d[3] << 16); v.w = (d[3] >> 16) | (d[4] << 16);
+                } else {
+                    v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
+                }
+                if (n < 8) {   // the dwords may carry the next row's first elements
+                    uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int keep = n - 2 * j;   // valid elements in word j
+                        vw[j] = keep >= 2 ? vw[j] : keep == 1 ? (vw[j] & 0xffffu) : 0u;
+                    }
+                }
+            }
         }
         *reinterpret_cast<u32x4*>(out + r * ld + c) = v;
     }
@@ -1316,6 +1706,8 @@ struct GemmPlan {
     int64_t Kp, lda, ldb; // K as the kernel sees it, row lengths of the operands as the kernel sees them
     bool copy_a, copy_b;
     size_t a_bytes, b_bytes;
+    int sk_split;         // path 2: K pieces of a last-round tile (<= 1: plain grid launch)
+    size_t sk_bytes;      // slots + flags of gemm_sk256_kernel
 };
 
 inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
@@ -1334,6 +1726,10 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
         g.ldb = round_up(N, 8);
         g.a_bytes = g.copy_a ? align_up((size_t)M * g.lda * 2, 256) : 0;
         g.b_bytes = g.copy_b ? align_up((size_t)g.Kp * g.ldb * 2, 256) : 0;
+        if (g.path == 2) {
+            g.sk_split = sk_split_of(gnnops_cdiv(M, BM2) * gnnops_cdiv(N, BN2), cu_count());
+            g.sk_bytes = g.sk_split > 1 ? sk_workspace_bytes(cu_count()) : 0;
+        }
     } else {
         // register staging bounds-checks every piece and reads rows of any length in the widest pieces their alignment
         // allows (load8<ALIGN>): no copies — these are the small, launch-bound problems (a batch of small graphs:
@@ -1353,7 +1749,7 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
 extern "C" size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M < 0 || N < 0 || K < 0) return 0;
     const GemmPlan g = gemm_plan(M, N, K);  // 16-bit operands only; fp32 needs none
-    return g.a_bytes + g.b_bytes;
+    return g.a_bytes + g.b_bytes + g.sk_bytes;
 }
 
 extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N,
@@ -1440,7 +1836,7 @@ extern "C" int gnnops_addmm_ld(const void* input, int64_t ldadd, const void* mat
         return gnnops_check_launch("addmm f32");
     }
     const GemmPlan g = gemm_plan(M, N, K);
-    const size_t need = g.a_bytes + g.b_bytes;
+    const size_t need = g.a_bytes + g.b_bytes + g.sk_bytes;
     GNNOPS_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), GNNOPS_EWORKSPACE, "addmm: workspace %zu < %zu",
                    workspace_bytes, need);
     int64_t lda = K, ldb = N;
@@ -1455,9 +1851,14 @@ extern "C" int gnnops_addmm_ld(const void* input, int64_t ldadd, const void* mat
         ldb = g.ldb;
         launch_pad(mat2, w, K, N, ldb, g.Kp, stream);  // rows K .. Kp-1 zero
         mat2 = w;
+        w += g.b_bytes;
     }
     GNNOPS_REQUIRE(g.path == 0 || K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0), GNNOPS_EUNSUPPORTED,
                    "addmm: operand base pointers must be 16-byte aligned");
+    if (g.path == 2 && g.sk_split > 1)
+        return dtype == GNNOPS_BF16
+                   ? launch_sk256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, w, g.sk_split, stream)
+                   : launch_sk256<__half, false>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, w, g.sk_split, stream);
     if (g.path == 2)
         return dtype == GNNOPS_BF16
                    ? launch_dma256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, stream)

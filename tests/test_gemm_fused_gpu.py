@@ -82,6 +82,71 @@ def test_addmm_big_tiles(gnnops, M, N, K, dname):
         assert bool((err <= bound).all()), f"max err/bound {(err / bound).max().item()}"
 
 
+@pytest.mark.parametrize("dname", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(4352, 4352, 192), (4352, 4096, 264), (4864, 4864, 128), (4249, 4249, 263),
+                                   (4100, 4600, 320), (4352, 4352, 2048)])
+def test_addmm_split_k_tail(gnnops, M, N, K, dname):
+    """More than one round of 256 x 256 tiles on the 256 CUs with a last round of at most half a round: the persistent kernel
+    (gemm_sk256_kernel) cuts the last round's tiles along K into 8 / 4 / 2 pieces (272 tiles: 16 left, 289: 33, 361: 105;
+    K = 264 -> 10 K-steps: pieces of one or two steps), partners exchange fp32 partial tiles through the workspace. Odd sizes put
+    edge tiles into the tail and run the pad copies of odd-length rows. Same bound as test_addmm_big_tiles; also equal
+    to the plain-grid kernel's result up to one rounding of the output type (the pieces are summed in a different order)."""
+    import os
+    g = torch.Generator().manual_seed(6)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    B = (torch.rand(K, N, generator=g) * 2 - 1 + torch.arange(N).float().view(1, N) / N).to(TORCH_DT[dname])
+    C = (torch.rand(M, N, generator=g) * 2 - 1).to(TORCH_DT[dname])
+    L = gnnops._lib.load()
+    plan_ws = L.gnnops_addmm_workspace_bytes(M, N, K)
+    os.environ["GNNOPS_GEMM_SK"] = "0"
+    try:
+        assert plan_ws > L.gnnops_addmm_workspace_bytes(M, N, K) + (200 << 20) // 4, "the split-K path was not planned"
+        plain = gnnops.addmm(C.cuda(), A.cuda(), B.cuda()).cpu()
+    finally:
+        del os.environ["GNNOPS_GEMM_SK"]
+    bound_acc = 4 * K * 2.0 ** -24 * (A.double().abs() @ B.double().abs())
+    prod = A.double() @ B.double()
+    for inp in (C, None):
+        got = gnnops.addmm(inp.cuda(), A.cuda(), B.cuda()) if inp is not None else gnnops.matmul(A.cuda(), B.cuda())
+        ref = prod + (inp.double() if inp is not None else 0)
+        err = (got.cpu().double() - ref).abs()
+        bound = EPS_OUT[dname] * ref.abs() + bound_acc + 1e-30
+        assert bool((err <= bound).all()), f"max err/bound {(err / bound).max().item()}"
+        if inp is not None:
+            ulp = 2 * EPS_OUT[dname] * plain.double().abs() + 1e-30
+            assert bool(((got.cpu().double() - plain.double()).abs() <= ulp + 2 * bound_acc).all())
+
+
+def test_addmm_split_k_tail_identity(gnnops):
+    """I @ B and B @ I with a split last round: every piece but one adds exact zeros, the result is B bit for bit."""
+    n = 4352
+    B = (torch.arange(n * n).view(n, n) % 251).to(torch.bfloat16)
+    I = torch.eye(n, dtype=torch.bfloat16)
+    assert torch.equal(gnnops.matmul(I.cuda(), B.cuda()).cpu(), B)
+    assert torch.equal(gnnops.matmul(B.cuda(), I.cuda()).cpu(), B)
+    for _ in range(3):   # the flags are cleared per launch: back-to-back calls sharing a workspace address
+        assert torch.equal(gnnops.addmm(B.cuda(), I.cuda(), B.cuda()).cpu(), (B.float() * 2).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(513, 517, 333), (600, 700, 257), (1023, 515, 1001)])
+def test_addmm_pad_copies_of_odd_rows(gnnops, M, N, K):
+    """pad_rows_kernel<2>: rows of odd length are read as whole dwords and shifted; the last row's last piece must not
+    read past the matrix and elements past a row's end must come out zero (they would otherwise carry the next row's
+    head into the K tail). Integer-valued operands: the product is exact, any leak shows."""
+    g = torch.Generator().manual_seed(8)
+    A = torch.randint(-2, 3, (M, K), generator=g).to(torch.float16)
+    B = torch.randint(-2, 3, (K, N), generator=g).to(torch.float16)
+    ref = (A.double() @ B.double())
+    assert ref.abs().max() < 2048
+    # operands at the very end of their allocations: a read past the last row would fault or pick up the guard values
+    a_buf = torch.full((M * K + 64,), 7.0, dtype=torch.float16, device="cuda")
+    b_buf = torch.full((K * N + 64,), 7.0, dtype=torch.float16, device="cuda")
+    a = a_buf[:M * K].view(M, K); a.copy_(A)
+    b = b_buf[:K * N].view(K, N); b.copy_(B)
+    got = gnnops.matmul(a, b).cpu().double()
+    assert torch.equal(got, ref)
+
+
 def test_addmm_big_tiles_identity(gnnops):
     n = 4096
     B = (torch.arange(n * n).view(n, n) % 251).to(torch.bfloat16)
