@@ -784,7 +784,7 @@ def addmm(input, mat1, mat2, *, beta=1, alpha=1):
     mat2 = mat2.contiguous()
     out = torch.empty((M, N), dtype=mat1.dtype, device=mat1.device)
     L = _lib.load()
-    ws_bytes = L.gnnops_addmm_workspace_bytes(M, N, K)
+    ws_bytes = L.gnnops_addmm_workspace_bytes(M, N, K) if mat1.dtype != torch.float32 else 0   # fp32 kernels use none
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat1.device) if ws_bytes else None
     with _on(mat1.device):
         rc = L.gnnops_addmm_ld(input.data_ptr() if input is not None else None, ld_input, mat1.data_ptr(), mat2.data_ptr(),

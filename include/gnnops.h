@@ -312,7 +312,11 @@ int gnnops_transpose_batched(const void* in, void* out, int64_t batch, int64_t R
  * mat2[K,N] (input == NULL: plain matmul). Row-major; dtype F16 / BF16 (fp32 MFMA accumulation, one rounding) or
  * F32 (exact-fp32 MFMA).
  * ------------------------------------------------------------------------------------------- */
-size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* 0 when K % 8 == 0 and N % 8 == 0 */
+/* Workspace of the 16-bit product (fp32 needs none; passing it is harmless): padded copies of operands whose rows are not
+ * 16-byte aligned or whose K is not a multiple of 64, plus — when more than one round of 256 x 256 tiles leaves a last round of
+ * at most half the CUs' worth — one 256 KiB fp32 slot per CU and a flag word each for the split-K tail (64 MiB on MI355X;
+ * contents need not survive the call, the flags are cleared on the stream by the call itself). 0 for small aligned problems. */
+size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out,
                  int64_t M, int64_t N, int64_t K, int dtype,
                  void* workspace, size_t workspace_bytes, gnnops_stream_t stream);
