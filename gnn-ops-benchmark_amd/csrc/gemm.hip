@@ -14,9 +14,10 @@
 //     tile in LDS and writes 16-B row pieces.
 // Three kernels (gemm_plan() picks): the register-staged, fully bounds-checked gemm_kernel for small problems; and for
 // anything of size the LDS-DMA pipelines gemm_dma4_kernel (128 x 128 tiles) and gemm_dma256_kernel (256 x 256, eight
-// waves) — global_load_lds_dwordx4 into four LDS stages of K = 32 with counted vmcnt waits. Operands whose rows are not
-// 16-B aligned, or whose K is not a whole number of K-tiles (the reference sweeps L = 1581 ... 8164), are first copied
-// into aligned, zero-padded rows (pad_rows_kernel, workspace).
+// waves; gemm_sk256_kernel = the same as persistent workgroups with the last round of tiles cut along K) —
+// global_load_lds_dwordx4 into four LDS stages of K = 32 with counted vmcnt waits. The reference sweeps L = 1581 ... 8164:
+// rows of any alignment are read where they lie and only the last K-tile comes from zero-filled side copies
+// (pad_tail_kernel); large A operands are still copied whole into aligned padded rows (pad_rows_kernel) — gemm_plan().
 #include "common.h"
 #include <stdlib.h>
 
@@ -265,10 +266,26 @@ constexpr int A4_BYTES = BM * BK4 * 2, B4_BYTES = BK4 * BN * 2, STAGE4_BYTES = A
 __device__ inline int a4_swz(int row) { return ((row >> 3) & 1) * 3; }
 __device__ inline int a4_off(int row, int ch) { return row * 64 + ((ch ^ a4_swz(row)) << 4); }
 
+// The LDS-DMA kernels read operand rows where they lie, whatever their alignment (global_load_lds_dwordx4 takes any
+// 2-byte-aligned source: tools/micro/dma_unaligned.hip). What they cannot read in place is the END of K: the last K-tile
+// must hold zeros past K on both operands (0 x garbage is not 0 when the garbage is Inf or NaN) and a B row's last
+// 16-B piece may run past the matrix. So the host copies only the last K-tile — A[:, Kmain:K] into At [M][64] and
+// B[Kmain:K, :] into Bt [64][ldb], zero-filled — and K-steps at or past Kmain take their pieces from there: the same
+// per-lane pointer plus a constant (element offsets; Kmain = K when there is no side copy).
+// An operand that IS a whole padded copy has no side copy (At / Bt null): its delta is 0.
+__device__ inline int64_t tail_delta_a(const uint16_t* A, const uint16_t* At, int64_t arow, int64_t lda, int64_t Kmain) {
+    return At ? (int64_t)(((intptr_t)At - (intptr_t)A) / 2) + arow * (64 - lda) - Kmain : 0;
+}
+__device__ inline int64_t tail_delta_b(const uint16_t* Bm, const uint16_t* Bt, int64_t ldb, int64_t Kmain) {
+    return Bt ? (int64_t)(((intptr_t)Bt - (intptr_t)Bm) / 2) - Kmain * ldb : 0;
+}
+
 template <typename T, bool IS_BF16>
 __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
                                                            const T* __restrict__ addend, T* __restrict__ C, int64_t M,
-                                                           int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd) {
+                                                           int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd,
+                                                           const uint16_t* __restrict__ At, const uint16_t* __restrict__ Bt,
+                                                           int64_t Kmain) {
     constexpr int EPI_BYTES = 4 * 64 * CS * 4;
     constexpr int SMEM_BYTES = (NST * STAGE4_BYTES > EPI_BYTES) ? NST * STAGE4_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
     // this wave's DMA pieces per stage: A pieces wave*2, wave*2+1 (16 rows x 64 B), B pieces wave*2, wave*2+1 (4 rows x 256 B)
     const uint16_t* a_src[2];
     const uint16_t* b_src[2];
+    int64_t a_dt[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         // rows past M re-read row M-1 and column chunks past ldb re-read the last chunk: in-bounds filler for outputs
@@ -293,18 +311,21 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const uint16_t* __res
         const int ar = (wave * 2 + p) * 16 + (lane >> 2);
         const int64_t arow = (m0 + ar < M) ? m0 + ar : M - 1;
         a_src[p] = A + arow * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
+        a_dt[p] = tail_delta_a(A, At, arow, lda, Kmain);
         const int br = (wave * 2 + p) * 4 + (lane >> 4);
         int64_t bcol = n0 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
-        if (bcol > ldb - 8) bcol = ldb - 8;
+        if (bcol > ((N - 1) & ~(int64_t)7)) bcol = (N - 1) & ~(int64_t)7;   // chunks past N re-read the last one that holds a column
         b_src[p] = Bm + (int64_t)br * ldb + bcol;
     }
+    const int64_t b_dt = tail_delta_b(Bm, Bt, ldb, Kmain);
     auto dma = [&](int stage, int64_t k0) {
         unsigned char* base = smem + stage * STAGE4_BYTES;
+        const bool in_tail = k0 >= Kmain;   // uniform: the last K-tile comes from the zero-padded side copies
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0 + (in_tail ? a_dt[p] : 0)),
                                              (__attribute__((address_space(3))) void*)(base + (wave * 2 + p) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb + (in_tail ? b_dt : 0)),
                                              (__attribute__((address_space(3))) void*)(base + A4_BYTES + (wave * 2 + p) * 1024),
                                              16, 0, 0);
         }
@@ -438,7 +459,9 @@ constexpr int EPI2_ROWS = 32;  // rows of a wave's 128 staged per epilogue round
 template <typename T, bool IS_BF16, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
                                                              const T* __restrict__ addend, T* __restrict__ C, int64_t M,
-                                                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd) {
+                                                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd,
+                                                             const uint16_t* __restrict__ At, const uint16_t* __restrict__ Bt,
+                                                             int64_t Kmain) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
     unsigned char* smem = smem256;
 
@@ -455,26 +478,29 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
     // DMA pieces of this wave per stage: A pieces 2w, 2w+1 (16 rows x 64 B); B pieces 2w, 2w+1 of 16 (half q>>3, 4 rows x 256 B)
     const uint16_t* a_src[2];
     const uint16_t* b_src[2];
+    int64_t a_dt[2];
     int b_dst[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int ar = (wave * 2 + p) * 16 + (lane >> 2);
         const int64_t arow = (m0 + ar < M) ? m0 + ar : M - 1;  // in-bounds filler, as in gemm_dma4_kernel
         a_src[p] = A + arow * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
+        a_dt[p] = tail_delta_a(A, At, arow, lda, Kmain);
         const int q = wave * 2 + p, half = q >> 3;
         const int br = (q & 7) * 4 + (lane >> 4);
         int64_t bcol = n0 + half * 128 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
-        if (bcol > ldb - 8) bcol = ldb - 8;
+        if (bcol > ((N - 1) & ~(int64_t)7)) bcol = (N - 1) & ~(int64_t)7;
         b_src[p] = Bm + (int64_t)br * ldb + bcol;
         b_dst[p] = A2_BYTES + half * (B2_BYTES / 2) + (q & 7) * 1024;
     }
+    const int64_t b_dt = tail_delta_b(Bm, Bt, ldb, Kmain);
     auto dma_a = [&](int stage, int64_t k0, int p) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0 + (k0 >= Kmain ? a_dt[p] : 0)),
                                          (__attribute__((address_space(3))) void*)(smem + stage * STAGE2_BYTES + (wave * 2 + p) * 1024),
                                          16, 0, 0);
     };
     auto dma_b = [&](int stage, int64_t k0, int p) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb + (k0 >= Kmain ? b_dt : 0)),
                                          (__attribute__((address_space(3))) void*)(smem + stage * STAGE2_BYTES + b_dst[p]), 16, 0, 0);
     };
     auto dma = [&](int stage, int64_t k0) {
@@ -714,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_kernel(const uint16_t* __r
 
 template <typename T, bool IS_BF16, int VAR>
 int launch_dma256_var(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K,
-                  int64_t lda, int64_t ldb, int64_t ldadd, hipStream_t stream) {
+                  int64_t lda, int64_t ldb, int64_t ldadd, const uint16_t* at, const uint16_t* bt, int64_t Kmain, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma256_kernel<T, IS_BF16, VAR>),
@@ -724,16 +750,16 @@ int launch_dma256_var(const void* input, const void* mat1, const void* mat2, voi
     }
     hipLaunchKernelGGL((gemm_dma256_kernel<T, IS_BF16, VAR>), dim3((unsigned)gnnops_cdiv(N, BN2), (unsigned)gnnops_cdiv(M, BM2)), dim3(512),
                        GEMM256_SMEM, stream, (const uint16_t*)mat1, (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K,
-                       lda, ldb, ldadd);
+                       lda, ldb, ldadd, at, bt, Kmain);
     return gnnops_check_launch("addmm");
 }
 
 template <typename T, bool IS_BF16>
 int launch_dma256(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K,
-                  int64_t lda, int64_t ldb, int64_t ldadd, hipStream_t stream) {
+                  int64_t lda, int64_t ldb, int64_t ldadd, const uint16_t* at, const uint16_t* bt, int64_t Kmain, hipStream_t stream) {
     const char* var = getenv("GNNOPS_GEMM_VAR");
-    if (var && var[0] == '1') return launch_dma256_var<T, IS_BF16, 1>(input, mat1, mat2, out, M, N, K, lda, ldb, ldadd, stream);
-    return launch_dma256_var<T, IS_BF16, 2>(input, mat1, mat2, out, M, N, K, lda, ldb, ldadd, stream);
+    if (var && var[0] == '1') return launch_dma256_var<T, IS_BF16, 1>(input, mat1, mat2, out, M, N, K, lda, ldb, ldadd, at, bt, Kmain, stream);
+    return launch_dma256_var<T, IS_BF16, 2>(input, mat1, mat2, out, M, N, K, lda, ldb, ldadd, at, bt, Kmain, stream);
 }
 
 // ---- split-K tail over the same 256 x 256 tiles: ONE persistent workgroup per CU --------------------------------------
@@ -772,8 +798,10 @@ template <typename T, bool IS_BF16>
 __global__ __launch_bounds__(512, 2) void gemm_sk256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm,
                                                             const T* __restrict__ addend, T* __restrict__ C, int64_t M,
                                                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldadd,
-                                                            float* __restrict__ slots, unsigned* __restrict__ flags,
-                                                            int tiles_m, int tiles_n, int dp_tiles, int tail_tiles, int split, int order) {
+                                                            const uint16_t* __restrict__ At, const uint16_t* __restrict__ Bt,
+                                                            int64_t Kmain, float* __restrict__ slots,
+                                                            unsigned* __restrict__ flags, int tiles_m, int tiles_n, int dp_tiles,
+                                                            int tail_tiles, int split, int order) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
     unsigned char* smem = smem256;
     __shared__ int poisoned;
@@ -842,28 +870,32 @@ __global__ __launch_bounds__(512, 2) void gemm_sk256_kernel(const uint16_t* __re
 
         const uint16_t* a_src[2];
         const uint16_t* b_src[2];
+        int64_t a_dt[2];
         int b_dst[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int ar = (wave * 2 + p) * 16 + (lane >> 2);
             const int64_t arow = (m0 + ar < M) ? m0 + ar : M - 1;
-            a_src[p] = A + arow * lda + kb * BK4 + (((lane & 3) ^ a4_swz(ar)) << 3);
+            a_src[p] = A + arow * lda + (((lane & 3) ^ a4_swz(ar)) << 3);
+            a_dt[p] = tail_delta_a(A, At, arow, lda, Kmain);
             const int q = wave * 2 + p, half = q >> 3;
             const int br = (q & 7) * 4 + (lane >> 4);
             int64_t bcol = n0 + half * 128 + (((lane & 15) ^ (((br & 3) << 2) | ((br >> 2) & 3))) << 3);
-            if (bcol > ldb - 8) bcol = ldb - 8;
-            b_src[p] = Bm + (kb * BK4 + br) * ldb + bcol;
+            if (bcol > ((N - 1) & ~(int64_t)7)) bcol = (N - 1) & ~(int64_t)7;
+            b_src[p] = Bm + (int64_t)br * ldb + bcol;
             b_dst[p] = A2_BYTES + half * (B2_BYTES / 2) + (q & 7) * 1024;
         }
+        const int64_t b_dt = tail_delta_b(Bm, Bt, ldb, Kmain);
         auto dma_tile = [&](int64_t tn_) {
             const int stage = (int)(tn_ & (NST - 1));
-            const int64_t k0 = (tn_ < ksteps ? tn_ : ksteps - 1) * BK4;
+            const int64_t k0 = (kb + (tn_ < ksteps ? tn_ : ksteps - 1)) * BK4;
+            const bool in_tail = k0 >= Kmain;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0 + (in_tail ? a_dt[p] : 0)),
                                                  (__attribute__((address_space(3))) void*)(smem + stage * STAGE2_BYTES + (wave * 2 + p) * 1024),
                                                  16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[p] + k0 * ldb + (in_tail ? b_dt : 0)),
                                                  (__attribute__((address_space(3))) void*)(smem + stage * STAGE2_BYTES + b_dst[p]), 16, 0, 0);
             }
         };
@@ -1069,7 +1101,8 @@ inline size_t sk_workspace_bytes(int G) { return (size_t)G * SK_SLOT_FLOATS * 4 
 
 template <typename T, bool IS_BF16>
 int launch_sk256(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K, int64_t lda,
-                 int64_t ldb, int64_t ldadd, void* sk_ws, int split, hipStream_t stream) {
+                 int64_t ldb, int64_t ldadd, const uint16_t* at, const uint16_t* bt, int64_t Kmain, void* sk_ws, int split,
+                 hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk256_kernel<T, IS_BF16>),
@@ -1085,7 +1118,7 @@ int launch_sk256(const void* input, const void* mat1, const void* mat2, void* ou
     const int order = od ? atoi(od) : 3;
     const int tail_tiles = (int)((int64_t)tiles_m * tiles_n % G), dp_tiles = tiles_m * tiles_n - tail_tiles;
     hipLaunchKernelGGL((gemm_sk256_kernel<T, IS_BF16>), dim3((unsigned)G), dim3(512), GEMM256_SMEM, stream, (const uint16_t*)mat1,
-                       (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K, lda, ldb, ldadd, (float*)sk_ws, flags, tiles_m,
+                       (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K, lda, ldb, ldadd, at, bt, Kmain, (float*)sk_ws, flags, tiles_m,
                        tiles_n, dp_tiles, tail_tiles, split, order);
     return gnnops_check_launch("addmm stream-K");
 }
@@ -1693,6 +1726,24 @@ inline void launch_pad(const void* in, void* out, int64_t rows, int64_t cols, in
         hipLaunchKernelGGL(pad_rows_kernel<2>, grid, dim3(256), 0, stream, i, o, rows, cols, ld, rows_out);
 }
 
+// The last K-tile of both operands, zero-filled (see tail_delta_a): At[r][c] = A[r][Kmain + c] for c < K - Kmain, Bt[k][c] =
+// B[Kmain + k][c] for k < K - Kmain; everything else 0. One launch; 2-byte loads (a megabyte or two in all).
+__global__ void pad_tail_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Bm, uint16_t* __restrict__ At,
+                                uint16_t* __restrict__ Bt, int64_t na, int64_t N, int64_t K, int64_t Kmain, int64_t bt_elems) {
+    const int64_t total = na + bt_elems;   // na = M * 64, or 0 when A is a whole padded copy; likewise bt_elems
+    const int tail = (int)(K - Kmain);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < na) {
+            const int64_t r = i >> 6;
+            const int c = (int)(i & 63);
+            At[i] = c < tail ? A[r * K + Kmain + c] : (uint16_t)0;
+        } else {
+            const int64_t j = i - na, k = j / N, c = j - k * N;
+            Bt[j] = k < tail ? Bm[(Kmain + k) * N + c] : (uint16_t)0;   // k >= 64: the slack behind the last row
+        }
+    }
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -1704,11 +1755,27 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 struct GemmPlan {
     int path;             // 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 2 LDS-DMA 256 x 256
     int64_t Kp, lda, ldb; // K as the kernel sees it, row lengths of the operands as the kernel sees them
-    bool copy_a, copy_b;
-    size_t a_bytes, b_bytes;
+    int64_t Kmain;        // K-steps at or past this come from the side copies of the last K-tile (== Kp: there are none)
+    bool copy_a, copy_b;  // whole padded copies
+    bool tail_a, tail_b;  // side copies of the last K-tile only
+    size_t a_bytes, b_bytes, at_bytes, bt_bytes;
     int sk_split;         // path 2: K pieces of a last-round tile (<= 1: plain grid launch)
     size_t sk_bytes;      // slots + flags of gemm_sk256_kernel
 };
+
+// Whole padded copies or in-place reads? Measured over the reference's sweep (tools/time_gemm_pad.py,
+// profiles/round3_f_gemm_pad_modes.txt): B read in place costs nothing at any size (256-B row pieces); A in place (64-B
+// row pieces at a pitch that is no multiple of a cache line) costs 2 % of the product at L = 4684 and 15-20 % at L = 8045,
+// so from ~30 M elements on A is copied into padded rows (a copy is L^2, the penalty L^3). The 128 x 128 kernel moves twice
+// the bytes per flop: once there is more than one workgroup per CU both operands are copied.
+inline void gemm_copy_whole(int64_t M, int64_t N, int64_t K, int path, bool& a, bool& b) {
+    if (path == 1) {
+        a = b = gnnops_cdiv(M, BM) * gnnops_cdiv(N, BN) > cu_count();
+        return;
+    }
+    a = M * K >= 30000000;
+    b = false;
+}
 
 inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
     GemmPlan g{};
@@ -1719,13 +1786,31 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
         const char* mn = getenv("GNNOPS_GEMM_MIN256");  // A/B: least number of 256 x 256 tiles that takes the big-tile kernel
         const int64_t min256 = mn ? atoll(mn) : 128;  // measured: 144 tiles 0.062 vs 0.086 ms, 100 tiles 0.056 vs 0.046 (tools/time_gemm_tiles.py)
         g.path = (gnnops_cdiv(M, BM2) * gnnops_cdiv(N, BN2) >= min256 && !(sw && sw[0] == '3')) ? 2 : 1;
+        // Operands are read in place where that is cheaper, with only the last K-tile copied (zeros past K; a B row's last
+        // 16-B piece may run into the next row, and behind B's very last row there is no next row), or copied whole into
+        // aligned zero-padded rows. GNNOPS_GEMM_PAD = full | a | b | none forces a choice (tools/time_gemm_pad.py).
+        const bool need = K % 64 != 0 || N % 8 != 0;
+        const bool misaligned = K % 8 != 0 || N % 8 != 0;
+        const char* pd = getenv("GNNOPS_GEMM_PAD");
+        bool whole_a = false, whole_b = false;
+        if (pd && pd[0] == 'f') whole_a = whole_b = true;
+        else if (pd && pd[0] == 'a') whole_a = true;
+        else if (pd && pd[0] == 'b') whole_b = true;
+        else if (pd && pd[0] == 'n') whole_a = whole_b = false;
+        else gemm_copy_whole(M, N, K, g.path, whole_a, whole_b);
         g.Kp = round_up(K, 64);
-        g.copy_a = K % 64 != 0;
-        g.copy_b = K % 64 != 0 || N % 8 != 0;
-        g.lda = g.Kp;
-        g.ldb = round_up(N, 8);
+        g.copy_a = whole_a && (K % 64 != 0 || K % 8 != 0);
+        g.copy_b = whole_b && (K % 64 != 0 || N % 8 != 0);
+        g.lda = g.copy_a ? g.Kp : K;
+        g.ldb = g.copy_b ? round_up(N, 8) : N;
+        g.tail_a = need && !g.copy_a;
+        g.tail_b = need && !g.copy_b;
+        g.Kmain = (g.tail_a || g.tail_b) ? (K % 64 ? K - K % 64 : K - 64) : g.Kp;
         g.a_bytes = g.copy_a ? align_up((size_t)M * g.lda * 2, 256) : 0;
         g.b_bytes = g.copy_b ? align_up((size_t)g.Kp * g.ldb * 2, 256) : 0;
+        g.at_bytes = g.tail_a ? align_up((size_t)M * 64 * 2, 256) : 0;
+        g.bt_bytes = g.tail_b ? align_up(((size_t)64 * N + 8) * 2, 256) : 0;
+        (void)misaligned;
         if (g.path == 2) {
             g.sk_split = sk_split_of(gnnops_cdiv(M, BM2) * gnnops_cdiv(N, BN2), cu_count());
             g.sk_bytes = g.sk_split > 1 ? sk_workspace_bytes(cu_count()) : 0;
@@ -1736,6 +1821,7 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
         // [9134, 11] @ [11, 44]), where two pad launches cost more than the product
         g.path = 0;
         g.Kp = K;
+        g.Kmain = K;
         g.copy_a = g.copy_b = false;
         g.lda = K;
         g.ldb = N;
@@ -1749,7 +1835,7 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
 extern "C" size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M < 0 || N < 0 || K < 0) return 0;
     const GemmPlan g = gemm_plan(M, N, K);  // 16-bit operands only; fp32 needs none
-    return g.a_bytes + g.b_bytes + g.sk_bytes;
+    return g.a_bytes + g.b_bytes + g.at_bytes + g.bt_bytes + g.sk_bytes;
 }
 
 extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N,
@@ -1836,41 +1922,53 @@ extern "C" int gnnops_addmm_ld(const void* input, int64_t ldadd, const void* mat
         return gnnops_check_launch("addmm f32");
     }
     const GemmPlan g = gemm_plan(M, N, K);
-    const size_t need = g.a_bytes + g.b_bytes + g.sk_bytes;
+    const size_t need = g.a_bytes + g.b_bytes + g.at_bytes + g.bt_bytes + g.sk_bytes;
     GNNOPS_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), GNNOPS_EWORKSPACE, "addmm: workspace %zu < %zu",
                    workspace_bytes, need);
-    int64_t lda = K, ldb = N;
+    int64_t lda = g.lda, ldb = g.ldb;
     char* w = (char*)workspace;
+    const uint16_t* at = nullptr;   // null: the operand is a whole padded copy (or there is no tail at all)
+    const uint16_t* bt = nullptr;
+    const void* a_orig = mat1;
+    const void* b_orig = mat2;
     if (g.copy_a) {
-        lda = g.lda;
         launch_pad(mat1, w, M, K, lda, M, stream);
         mat1 = w;
         w += g.a_bytes;
     }
     if (g.copy_b) {
-        ldb = g.ldb;
         launch_pad(mat2, w, K, N, ldb, g.Kp, stream);  // rows K .. Kp-1 zero
         mat2 = w;
         w += g.b_bytes;
     }
-    GNNOPS_REQUIRE(g.path == 0 || K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0), GNNOPS_EUNSUPPORTED,
-                   "addmm: operand base pointers must be 16-byte aligned");
+    if (g.path != 0 && (g.tail_a || g.tail_b)) {
+        if (g.tail_a) at = (const uint16_t*)w;
+        if (g.tail_b) bt = (const uint16_t*)(w + g.at_bytes);
+        const int64_t at_elems = g.tail_a ? M * 64 : 0, bt_elems = g.tail_b ? 64 * N + 8 : 0;
+        hipLaunchKernelGGL(pad_tail_kernel, dim3(gnnops_grid_cap(gnnops_cdiv(at_elems + bt_elems, 256), 256 * 8)), dim3(256), 0, stream,
+                           (const uint16_t*)a_orig, (const uint16_t*)b_orig, (uint16_t*)w, (uint16_t*)(w + g.at_bytes), at_elems, N, K,
+                           g.Kmain, bt_elems);
+        w += g.at_bytes + g.bt_bytes;
+    }
+    GNNOPS_REQUIRE(g.path == 0 || !(g.copy_a || g.copy_b) || K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0),
+                   GNNOPS_EUNSUPPORTED, "addmm: operand base pointers must be 16-byte aligned");
     if (g.path == 2 && g.sk_split > 1)
         return dtype == GNNOPS_BF16
-                   ? launch_sk256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, w, g.sk_split, stream)
-                   : launch_sk256<__half, false>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, w, g.sk_split, stream);
+                   ? launch_sk256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, at, bt, g.Kmain, w, g.sk_split, stream)
+                   : launch_sk256<__half, false>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, at, bt, g.Kmain, w, g.sk_split, stream);
     if (g.path == 2)
         return dtype == GNNOPS_BF16
-                   ? launch_dma256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, stream)
-                   : launch_dma256<__half, false>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, stream);
+                   ? launch_dma256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, at, bt, g.Kmain, stream)
+                   : launch_dma256<__half, false>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, at, bt, g.Kmain, stream);
     dim3 grid((unsigned)gnnops_cdiv(N, BN), (unsigned)gnnops_cdiv(M, BM));
     if (g.path == 1) {
         if (dtype == GNNOPS_BF16)
             hipLaunchKernelGGL((gemm_dma4_kernel<__hip_bfloat16, true>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, g.Kp, lda, ldb, ldadd);
+                               (const uint16_t*)mat2, (const __hip_bfloat16*)input, (__hip_bfloat16*)out, M, N, g.Kp, lda, ldb, ldadd,
+                               at, bt, g.Kmain);
         else
             hipLaunchKernelGGL((gemm_dma4_kernel<__half, false>), grid, dim3(256), 0, stream, (const uint16_t*)mat1,
-                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, g.Kp, lda, ldb, ldadd);
+                               (const uint16_t*)mat2, (const __half*)input, (__half*)out, M, N, g.Kp, lda, ldb, ldadd, at, bt, g.Kmain);
         return gnnops_check_launch("addmm");
     }
     // path 0: the widest piece both operands' rows allow

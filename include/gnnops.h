@@ -312,8 +312,8 @@ int gnnops_transpose_batched(const void* in, void* out, int64_t batch, int64_t R
  * mat2[K,N] (input == NULL: plain matmul). Row-major; dtype F16 / BF16 (fp32 MFMA accumulation, one rounding) or
  * F32 (exact-fp32 MFMA).
  * ------------------------------------------------------------------------------------------- */
-/* Workspace of the 16-bit product (fp32 needs none; passing it is harmless): padded copies of operands whose rows are not
- * 16-byte aligned or whose K is not a multiple of 64, plus — when more than one round of 256 x 256 tiles leaves a last round of
+/* Workspace of the 16-bit product (fp32 needs none; passing it is harmless): zero-filled copies of the last K-tile of each
+ * operand when K is not a multiple of 64 or N not a multiple of 8 (a whole padded copy of a large mat1 instead), plus — when more than one round of 256 x 256 tiles leaves a last round of
  * at most half the CUs' worth — one 256 KiB fp32 slot per CU and a flag word each for the split-K tail (64 MiB on MI355X;
  * contents need not survive the call, the flags are cleared on the stream by the call itself). 0 for small aligned problems. */
 size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K);

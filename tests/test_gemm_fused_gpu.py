@@ -147,6 +147,39 @@ def test_addmm_pad_copies_of_odd_rows(gnnops, M, N, K):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("dname", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(1581, 1581, 1581), (700, 900, 257), (513, 520, 512), (1030, 1027, 320), (4249, 4249, 263),
+                                   (3000, 3100, 264), (2050, 4100, 1000), (515, 519, 4101)])
+def test_addmm_operands_read_in_place(gnnops, M, N, K, dname):
+    """The LDS-DMA kernels read rows of any alignment where they lie and take only the LAST K-tile from zero-filled side
+    copies (K % 64 != 0, or N % 8 != 0 where a B row's last 16-B piece would run past the matrix). The products and their
+    order are those of the whole-matrix padded copies (GNNOPS_GEMM_PAD=full, the earlier path): bit-identical results.
+    Operands sit at the very end of their allocations with a NaN guard behind them: a read past the end that reached an
+    output would show."""
+    import os
+    g = torch.Generator().manual_seed(9)
+    dt = TORCH_DT[dname]
+    def at_end(rows, cols):
+        buf = torch.full((rows * cols + 40,), float("nan"), dtype=dt, device="cuda")
+        v = buf[:rows * cols].view(rows, cols)
+        v.copy_((torch.rand(rows, cols, generator=g) * 2 - 1).to(dt))
+        return v
+    A, B, C = at_end(M, K), at_end(K, N), at_end(M, N)
+    got = gnnops.addmm(C, A, B)
+    os.environ["GNNOPS_GEMM_PAD"] = "full"
+    try:
+        ref = gnnops.addmm(C, A, B)
+    finally:
+        del os.environ["GNNOPS_GEMM_PAD"]
+    assert not torch.isnan(got).any()
+    assert torch.equal(got, ref)
+    rows = torch.randint(0, M, (32,), generator=g).cuda()
+    ref64 = C[rows].double() + A[rows].double() @ B.double()
+    err = (got[rows].double() - ref64).abs()
+    bound = EPS_OUT[dname] * ref64.abs() + 4 * K * 2.0 ** -24 * (A[rows].double().abs() @ B.double().abs()) + 1e-30
+    assert bool((err <= bound).all())
+
+
 def test_addmm_big_tiles_identity(gnnops):
     n = 4096
     B = (torch.arange(n * n).view(n, n) % 251).to(torch.bfloat16)
