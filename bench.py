@@ -557,6 +557,17 @@ def config3_leg(torch, gnnops):
     ms = _event_ms(torch, lambda: gnnops.addmm(c, a, b), 20)
     res["addmm_square_bf16"] = {"shape": f"{L}^3", "ms": round(ms, 4), "TFLOPs": round(2 * L ** 3 / ms / 1e9, 1),
                                 "mfma_frac_of_dense_peak": round(2 * L ** 3 / ms / 1e9 / MFMA_PEAK_TFLOPS, 4)}
+    del a, b, c
+    # the reference's own protocol: fp16, square, L = int(sqrt(x)) (benchmark_native_addmm.py:23-27) — odd row lengths, K not a
+    # multiple of the K-tile, tile counts that do not fill whole rounds of CUs (289, 529, 784 tiles: split-K tail)
+    sweep = {}
+    for L in (1581, 4249, 5797, 7011, 8164):
+        a, b, c = [(torch.rand(L, L, generator=g, device=dev) * 2 - 1).half() for _ in range(3)]
+        gnnops.addmm(c, a, b)
+        ms = _event_ms(torch, lambda: gnnops.addmm(c, a, b), 10)
+        sweep[str(L)] = {"ms": round(ms, 4), "TFLOPs": round(2 * L ** 3 / ms / 1e9, 1)}
+        del a, b, c
+    res["addmm_reference_lengths_fp16"] = sweep
     return res
 
 

@@ -1832,10 +1832,21 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
 
 }  // namespace
 
-extern "C" size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-    if (M < 0 || N < 0 || K < 0) return 0;
+// the row-tile index travels in gridDim.y (< 65536): taller problems (a node-feature matrix of BASELINE config 2's 10M rows)
+// run as slabs of whole tiles, one after the other on the stream, sharing the workspace
+constexpr int64_t GEMM_SLAB = (int64_t)65280 * 128;
+
+static size_t plan_bytes(int64_t M, int64_t N, int64_t K) {
     const GemmPlan g = gemm_plan(M, N, K);  // 16-bit operands only; fp32 needs none
     return g.a_bytes + g.b_bytes + g.at_bytes + g.bt_bytes + g.sk_bytes;
+}
+
+extern "C" size_t gnnops_addmm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M < 0 || N < 0 || K < 0) return 0;
+    if (M <= GEMM_SLAB) return plan_bytes(M, N, K);
+    // every slab plans for itself (tile count, copies, split-K tail): the largest need of the two slab heights that occur
+    const size_t whole = plan_bytes(GEMM_SLAB, N, K), rest = M % GEMM_SLAB ? plan_bytes(M % GEMM_SLAB, N, K) : 0;
+    return whole > rest ? whole : rest;
 }
 
 extern "C" int gnnops_addmm(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N,
@@ -1856,9 +1867,7 @@ extern "C" int gnnops_addmm_ld(const void* input, int64_t ldadd, const void* mat
                    "addmm: an input row pitch other than 0 or N must be a multiple of 16 bytes (got %lld elements)", (long long)ldadd);
     if (M * N == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(out && (K == 0 || (mat1 && mat2)), GNNOPS_EINVAL, "addmm: null pointer");
-    // the row-tile index travels in gridDim.y (< 65536): taller problems (a node-feature matrix of BASELINE config 2's
-    // 10M rows) run as slabs of whole tiles, one after the other on the stream, sharing the workspace
-    constexpr int64_t SLAB = (int64_t)65280 * BM;
+    constexpr int64_t SLAB = GEMM_SLAB;
     if (M > SLAB) {
         const size_t es = dtype == GNNOPS_F32 ? 4 : 2;
         for (int64_t r0 = 0; r0 < M; r0 += SLAB) {

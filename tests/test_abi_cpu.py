@@ -43,6 +43,16 @@ def test_workspace_queries_are_host_only():
     assert lib.gnnops_scatter_elementwise_workspace_bytes(1, 100, 8, 1, 0) >= 3200   # f16 sum: fp32 scratch
     assert lib.gnnops_scatter_elementwise_workspace_bytes(1, 100, 8, 1, 1) >= 6400   # f16 mean: + counts
     assert lib.gnnops_fused_select_sum_workspace_bytes() > 0
+    # 16-bit addmm (csrc/gemm.hip gemm_plan): nothing for whole K-tiles and 16-B rows in whole rounds of tiles; side copies
+    # of the last K-tile otherwise; 256 KiB per CU when the last round of 256 x 256 tiles is cut along K; and a problem
+    # taller than one grid is planned slab by slab (the largest need of the slab heights that occur)
+    ws = lib.gnnops_addmm_workspace_bytes
+    assert ws(4096, 4096, 4096) == 0
+    assert 0 < ws(4096, 4096, 4100) < (8 << 20)
+    assert ws(4352, 4352, 4096) >= 256 * (256 << 10)          # 289 tiles: 33 left over
+    slab = 65280 * 128
+    assert ws(slab + 777, 512, 264) >= max(ws(slab, 512, 264), ws(777, 512, 264))
+    assert ws(2 * slab + 4352, 4352, 264) >= ws(4352, 4352, 264) >= 256 * (256 << 10)
 
 
 def test_cpu_tensors_are_refused_not_emulated():

@@ -50,6 +50,32 @@ def test_scatter_index_select_addmm_in_a_graph(gnnops):
         gnnops.set_plan_cache(True)
 
 
+def test_split_k_addmm_in_a_graph(gnnops):
+    """289 tiles of 256 x 256: the persistent kernel with a split last round (csrc/gemm.hip gemm_sk256_kernel). Its flag words
+    are cleared by a memset node of the same capture, the partner hand-off is device work: replays see new operands and
+    reproduce the eager result bit for bit; K = 300 adds the side copies of the last K-tile."""
+    M = N = 4352
+    K = 300
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    a = (torch.rand(M, K, generator=gen, device="cuda") - 0.5).half()
+    b = (torch.rand(K, N, generator=gen, device="cuda") - 0.5).half()
+    c = (torch.rand(M, N, generator=gen, device="cuda") - 0.5).half()
+    assert gnnops._lib.load().gnnops_addmm_workspace_bytes(M, N, K) >= 256 * (256 << 10)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gnnops.addmm(c, a, b)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = gnnops.addmm(c, a, b)
+    for trial in range(3):
+        a.copy_((torch.rand(M, K, generator=gen, device="cuda") - 0.5).half())
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, gnnops.addmm(c, a, b)), trial
+
+
 def test_message_passing_layer_in_a_graph(gnnops):
     """A whole layer (gnnops.conv: dense product + plan + fused edge pass) is launch-bound on a batch of small graphs
     (app_bm/benchmark_convs.py). With the plan cache OFF everything the layer does is device work on the current stream — the
