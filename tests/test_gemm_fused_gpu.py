@@ -128,6 +128,27 @@ def test_addmm_split_k_tail_identity(gnnops):
         assert torch.equal(gnnops.addmm(B.cuda(), I.cuda(), B.cuda()).cpu(), (B.float() * 2).to(torch.bfloat16))
 
 
+def test_addmm_split_k_tail_reuses_its_workspace(gnnops):
+    """Back-to-back calls get the same workspace addresses from the allocator, with different operands each time: a flag
+    or a partial tile that survived from the previous call would put a partner's OLD partial into the sum — an error of
+    whole units against the plain-grid kernel's result, where a correct sum differs by one rounding of the output."""
+    import os
+    M = N = 4352
+    K = 1024
+    g = torch.Generator(device="cuda").manual_seed(12)
+    b = (torch.rand(K, N, generator=g, device="cuda") - 0.5).half()
+    c = (torch.rand(M, N, generator=g, device="cuda") - 0.5).half()
+    for _ in range(8):
+        a = (torch.rand(M, K, generator=g, device="cuda") - 0.5).half()
+        got = gnnops.addmm(c, a, b)
+        os.environ["GNNOPS_GEMM_SK"] = "0"
+        try:
+            plain = gnnops.addmm(c, a, b)
+        finally:
+            del os.environ["GNNOPS_GEMM_SK"]
+        assert (got.float() - plain.float()).abs().max().item() <= 0.02
+
+
 @pytest.mark.parametrize("M,N,K", [(513, 517, 333), (600, 700, 257), (1023, 515, 1001)])
 def test_addmm_pad_copies_of_odd_rows(gnnops, M, N, K):
     """pad_rows_kernel<2>: rows of odd length are read as whole dwords and shifted; the last row's last piece must not
