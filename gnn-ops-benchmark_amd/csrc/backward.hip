@@ -132,7 +132,7 @@ extern "C" int gnnops_owner_counts(const int64_t* index, int64_t E, int64_t rows
     GNNOPS_REQUIRE(E >= 0 && rows_per_owner > 0 && owners >= 1 && owners <= 64, GNNOPS_EINVAL,
                    "owner_counts: bad argument (E=%lld per=%lld owners=%d)", (long long)E, (long long)rows_per_owner, owners);
     GNNOPS_REQUIRE(counts && (E == 0 || index), GNNOPS_EINVAL, "owner_counts: null pointer");
-    if (hipMemsetAsync(counts, 0, sizeof(int64_t) * owners, stream) != hipSuccess) return gnnops_check_launch("owner_counts memset");
+    if (gnnops_memset_async(counts, 0, sizeof(int64_t) * owners, stream) != hipSuccess) return gnnops_check_launch("owner_counts memset");
     if (E == 0) return GNNOPS_OK;
     const int grid = gnnops_grid_cap(gnnops_cdiv(E, 256 * 8), 256 * 8);
     hipLaunchKernelGGL(owner_counts_kernel, dim3(grid), dim3(256), 0, stream, index, E, rows_per_owner, owners,

@@ -406,7 +406,7 @@ int launch_bucket(const void* src, const uint32_t* keys, const uint32_t* vals, c
         const hub::Layout hl = hub::layout(E, K, want_arg);
         if (hub_ws_bytes >= hl.total) {
             hw = hub::make_ws(hub_ws, hl, E, want_arg);
-            if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+            if (gnnops_memset_async(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
             hub_on = 1;
         }
     }
@@ -626,7 +626,7 @@ extern "C" int gnnops_bucket_select_hubs(const void* input, const void* workspac
         const hub::Layout hl = hub::layout(E, 0, false);
         if (hub_workspace_bytes >= hl.total) {
             hw = hub::make_ws(hub_workspace, hl, E, false);
-            if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+            if (gnnops_memset_async(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
             hub_on = 1;
         }
     }

@@ -373,7 +373,7 @@ extern "C" int gnnops_graclus_rounds(const int64_t* rowptr, const int64_t* col, 
     hipStream_t stream = (hipStream_t)s;
     const int grid = gnnops_grid_cap(gnnops_cdiv(N, 256));
     for (int r = 0; r < rounds; ++r) {
-        if (hipMemsetAsync(d_active, 0, sizeof(int), stream) != hipSuccess) return gnnops_check_launch("graclus memset");
+        if (gnnops_memset_async(d_active, 0, sizeof(int), stream) != hipSuccess) return gnnops_check_launch("graclus memset");
         GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((graclus_propose_kernel<T>), dim3(grid), dim3(256), 0, stream, rowptr, col, (const T*)weight, N,
                                                   seed, cluster, proposal, d_active), "graclus")
         hipLaunchKernelGGL(graclus_match_kernel, dim3(grid), dim3(256), 0, stream, N, proposal, cluster);

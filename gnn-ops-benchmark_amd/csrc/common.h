@@ -30,6 +30,27 @@ static inline int gnnops_grid_cap(int64_t want, int64_t cap = 256 * 16) {
     return (int)(want < cap ? want : cap);
 }
 
+// ---- device-side clears ----
+// Counters, flags and row pointers are cleared by a KERNEL, never by hipMemsetAsync: inside a captured graph the runtime
+// turns hipMemsetAsync into a memset NODE, and the node that follows did not reliably see it (round 3: the split-K flags of
+// gemm.hip read as still set on 3 of 8 replays, tools/diag_sk_handoff.py; eager launches — where the runtime's memset is
+// a fill kernel anyway — never failed). `bytes` and the pointer must be multiples of 4; every byte gets `byte_value`.
+namespace {
+__global__ void gnnops_fill_words_kernel(uint32_t* __restrict__ p, uint32_t word, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = word;
+}
+}  // namespace
+static inline hipError_t gnnops_memset_async(void* p, int byte_value, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if (((uintptr_t)p | bytes) & 3) return hipErrorInvalidValue;
+    const uint32_t b = (uint32_t)(byte_value & 0xff), word = b | (b << 8) | (b << 16) | (b << 24);
+    const int64_t n = (int64_t)(bytes / 4);
+    const int64_t want = (n + 1023) / 1024;
+    hipLaunchKernelGGL(gnnops_fill_words_kernel, dim3((unsigned)(want < 1 ? 1 : want > 4096 ? 4096 : want)), dim3(256), 0, stream,
+                       (uint32_t*)p, word, n);
+    return hipGetLastError();
+}
+
 // ---- 16-byte vector type used for every wide global access ----
 struct __attribute__((aligned(16))) u32x4 { uint32_t x, y, z, w; };
 

@@ -394,7 +394,7 @@ int dispatch(int mode, const void* src, const int32_t* rowptr, const int32_t* pe
             const hub::Layout hl = hub::layout(E, K, true);   // two partial buffers: the statistics of passes 1 and 2
             if (hub_ws_bytes >= hl.total) {
                 hw = hub::make_ws(hub_ws, hl, E, true);
-                if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+                if (gnnops_memset_async(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
                 hub_on = 1;
             }
         }

@@ -539,7 +539,7 @@ int launch_vec(Args& a, hipStream_t stream) {
     a.kchunks = (int)gnnops_cdiv(lanes, (int64_t)1 << gshift);
     const int64_t items = (int64_t)a.kchunks * a.N;
     const int grid = gnnops_grid_cap(gnnops_cdiv(items, 256 >> gshift), 256 * 64);
-    if (a.hub_count && hipMemsetAsync(a.hub_count, 0, 8, stream) != hipSuccess) return gnnops_check_launch("edge_reduce hub memset");
+    if (a.hub_count && gnnops_memset_async(a.hub_count, 0, 8, stream) != hipSuccess) return gnnops_check_launch("edge_reduce hub memset");
     if (gshift == 6) hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, HAS_W, VEC, true>), dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((edge_reduce_kernel<T, F, MULTI, HAS_W, VEC, false>), dim3(grid), dim3(256), 0, stream, a);
     if (a.hub_count) {   // the hub passes find their own work on the device (counts are never read back); empty when there is no hub

@@ -726,7 +726,7 @@ extern "C" int gnnops_index_select_planned_hubs(const void* input, const int32_t
         const hub::Layout hl = hub::layout(E, 0, false);
         if (hub_workspace_bytes >= hl.total) {
             hw = hub::make_ws(hub_workspace, hl, E, false);
-            if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+            if (gnnops_memset_async(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
             hub_on = 1;
         }
     }
@@ -773,7 +773,7 @@ extern "C" int gnnops_fused_index_select_sum(const void* input, const int64_t* i
     GNNOPS_REQUIRE(B >= 0 && N >= 0 && K >= 0 && E >= 0, GNNOPS_EINVAL, "fused_index_select_sum: negative size");
     GNNOPS_REQUIRE(d_sum_f32 != nullptr, GNNOPS_EINVAL, "fused_index_select_sum: null output");
     if (B * E * K == 0) {
-        if (hipMemsetAsync(d_sum_f32, 0, sizeof(float), stream) != hipSuccess)
+        if (gnnops_memset_async(d_sum_f32, 0, sizeof(float), stream) != hipSuccess)
             return gnnops_check_launch("fused_index_select_sum memset");
         return GNNOPS_OK;
     }

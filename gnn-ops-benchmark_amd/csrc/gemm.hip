@@ -1099,10 +1099,6 @@ inline int sk_split_of(int64_t T, int G) {
 inline size_t sk_flag_bytes(int G) { return ((size_t)G * 4 + 1023) / 1024 * 1024; }
 inline size_t sk_workspace_bytes(int G) { return (size_t)G * SK_SLOT_FLOATS * 4 + sk_flag_bytes(G); }
 
-__global__ void sk_clear_kernel(unsigned* __restrict__ flags, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) flags[i] = 0u;
-}
-
 template <typename T, bool IS_BF16>
 int launch_sk256(const void* input, const void* mat1, const void* mat2, void* out, int64_t M, int64_t N, int64_t K, int64_t lda,
                  int64_t ldb, int64_t ldadd, const uint16_t* at, const uint16_t* bt, int64_t Kmain, void* sk_ws, int split,
@@ -1116,9 +1112,8 @@ int launch_sk256(const void* input, const void* mat1, const void* mat2, void* ou
     }
     const int G = cu_count();
     unsigned* flags = reinterpret_cast<unsigned*>((char*)sk_ws + (size_t)G * SK_SLOT_FLOATS * 4);
-    // cleared by a kernel of our own, not hipMemsetAsync: as a memset NODE of a captured graph the clear was not reliably
-    // seen by the pollers of the next node (tools/diag_sk_handoff.py: 3 of 8 replays read a partner's slot early)
-    hipLaunchKernelGGL(sk_clear_kernel, dim3(1), dim3(256), 0, stream, flags, (int)(sk_flag_bytes(G) / 4));
+    // cleared by a kernel, not a memset node (common.h gnnops_memset_async)
+    if (gnnops_memset_async(flags, 0, sk_flag_bytes(G), stream) != hipSuccess) return gnnops_check_launch("addmm flags");
     const int tiles_m = (int)gnnops_cdiv(M, BM2), tiles_n = (int)gnnops_cdiv(N, BN2);
     const char* od = getenv("GNNOPS_GEMM_SK_ORDER");  // A/B: bit 0 = workgroup id by XCD share, bit 1 = tile ids down bands of 8 rows
     const int order = od ? atoi(od) : 3;

@@ -202,7 +202,7 @@ extern "C" int gnnops_index_max(const int64_t* index, int64_t E, int64_t* d_max,
     GNNOPS_REQUIRE(d_max != nullptr, GNNOPS_EINVAL, "index_max: d_max is null");
     GNNOPS_REQUIRE(E >= 0 && (E == 0 || index != nullptr), GNNOPS_EINVAL, "index_max: bad index/E");
     // d_max = -1 (all bits set), then atomicMax over the data (stream-ordered, no sync)
-    if (hipMemsetAsync(d_max, 0xff, sizeof(int64_t), stream) != hipSuccess)
+    if (gnnops_memset_async(d_max, 0xff, sizeof(int64_t), stream) != hipSuccess)
         return gnnops_check_launch("index_max memset");
     if (E > 0) {
         int grid = gnnops_grid_cap(gnnops_cdiv(E, 256 * 8), 256);  // one workgroup per CU: 55 us against 75 us with 1024 or more (tools/time_index_max.py)
@@ -235,7 +235,7 @@ extern "C" int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N, int
                    "plan_build: E and N must be < 2^31 (got E=%lld N=%lld)", (long long)E, (long long)N);
     GNNOPS_REQUIRE(rowptr != nullptr, GNNOPS_EINVAL, "plan_build: rowptr is null");
     if (E == 0) {
-        if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 4, stream) != hipSuccess)
+        if (gnnops_memset_async(rowptr, 0, (size_t)(N + 1) * 4, stream) != hipSuccess)
             return gnnops_check_launch("plan_build memset");
         return GNNOPS_OK;
     }
@@ -276,7 +276,7 @@ extern "C" int gnnops_plan_build(const int64_t* index, int64_t E, int64_t N, int
         kin = kout; vin = vout; sorted_keys = kout;
     }
 
-    if (hipMemsetAsync(gap_count, 0, sizeof(unsigned int), stream) != hipSuccess)
+    if (gnnops_memset_async(gap_count, 0, sizeof(unsigned int), stream) != hipSuccess)
         return gnnops_check_launch("plan_build memset gap_count");
     {
         int grid = gnnops_grid_cap(gnnops_cdiv(E + 4, 1024));
@@ -328,7 +328,7 @@ extern "C" int gnnops_rowptr_from_sorted(const int64_t* sorted_index, int64_t E,
     GNNOPS_REQUIRE(E == 0 || sorted_index, GNNOPS_EINVAL, "rowptr_from_sorted: null index");
     unsigned int* gap_count = (unsigned int*)workspace;
     int32_t* gap_list = (int32_t*)((char*)workspace + 256);
-    if (hipMemsetAsync(gap_count, 0, sizeof(unsigned int), stream) != hipSuccess)
+    if (gnnops_memset_async(gap_count, 0, sizeof(unsigned int), stream) != hipSuccess)
         return gnnops_check_launch("rowptr_from_sorted memset");
     const int grid = gnnops_grid_cap(gnnops_cdiv(E + 4, 1024));
     hipLaunchKernelGGL(rowptr_kernel<int64_t>, dim3(grid), dim3(256), 0, stream, sorted_index, E, N, rowptr, gap_list, gap_count);

@@ -50,7 +50,6 @@ struct Layout1d {
 inline Layout1d layout1d(int64_t E, int64_t N) {
     Layout1d l{};
     const size_t tiles = (size_t)gnnops_cdiv(E > 0 ? E : 1, sortengine::TILE);
-    const size_t NB = (size_t)gnnops_cdiv(N > 0 ? N : 1, BUCKET);
     size_t o = 0;
     l.keys_a = o; o += align_up((size_t)E * 8, 256);
     l.keys_b = o; o += align_up((size_t)E * 8, 256);

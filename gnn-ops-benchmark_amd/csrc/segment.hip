@@ -333,7 +333,7 @@ int launch_seg(const void* src, const int32_t* rowptr, const int32_t* perm, void
             const hub::Layout hl = hub::layout(E, K, want_arg);
             if (hub_ws_bytes >= hl.total) {
                 hw = hub::make_ws(hub_ws, hl, E, want_arg);
-                if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+                if (gnnops_memset_async(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
                 hub_on = 1;
             }
         }

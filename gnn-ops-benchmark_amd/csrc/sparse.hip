@@ -229,7 +229,7 @@ extern "C" int gnnops_coalesce(const int64_t* row, const int64_t* col, const voi
     GNNOPS_REQUIRE(nnz < ((int64_t)1 << 32), GNNOPS_EUNSUPPORTED, "coalesce: nnz must be < 2^32");
     GNNOPS_REQUIRE(d_count != nullptr, GNNOPS_EINVAL, "coalesce: d_count is null");
     if (nnz == 0) {
-        if (hipMemsetAsync(d_count, 0, sizeof(int64_t), stream) != hipSuccess) return gnnops_check_launch("coalesce memset");
+        if (gnnops_memset_async(d_count, 0, sizeof(int64_t), stream) != hipSuccess) return gnnops_check_launch("coalesce memset");
         return GNNOPS_OK;
     }
     GNNOPS_REQUIRE(row && col && out_row && out_col, GNNOPS_EINVAL, "coalesce: null pointer");

@@ -180,7 +180,7 @@ int launch(const int32_t* rowptr, const int32_t* perm, const int64_t* col, const
             const hub::Layout hl = hub::layout(nnz, D, false);
             if (hub_ws_bytes >= hl.total) {
                 hw = hub::make_ws(hub_ws, hl, nnz, false);
-                if (hipMemsetAsync(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
+                if (gnnops_memset_async(hw.counters, 0, 8, stream) != hipSuccess) return gnnops_check_launch("hub memset");
                 hub_on = 1;
             }
         }

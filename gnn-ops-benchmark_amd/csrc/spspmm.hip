@@ -107,7 +107,7 @@ extern "C" int gnnops_spspmm_count(const int64_t* colA, int64_t nnzA, const int3
     GNNOPS_REQUIRE(workspace && workspace_bytes >= gnnops_spspmm_workspace_bytes(nnzA), GNNOPS_EWORKSPACE,
                    "spspmm_count: workspace too small");
     if (nnzA == 0) {
-        if (hipMemsetAsync(d_total, 0, sizeof(int64_t), stream) != hipSuccess) return gnnops_check_launch("spspmm memset");
+        if (gnnops_memset_async(d_total, 0, sizeof(int64_t), stream) != hipSuccess) return gnnops_check_launch("spspmm memset");
         return GNNOPS_OK;
     }
     GNNOPS_REQUIRE(colA && rowptrB, GNNOPS_EINVAL, "spspmm_count: null pointer");
