@@ -84,12 +84,13 @@ def test_addmm_big_tiles(gnnops, M, N, K, dname):
 
 @pytest.mark.parametrize("dname", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(4352, 4352, 192), (4352, 4096, 264), (4864, 4864, 128), (4249, 4249, 263),
-                                   (4100, 4600, 320), (4352, 4352, 2048)])
+                                   (4100, 4600, 320), (4352, 4352, 2048), (512, 37000, 320), (37000, 512, 328)])
 def test_addmm_split_k_tail(gnnops, M, N, K, dname):
     """More than one round of 256 x 256 tiles on the 256 CUs with a last round of at most half a round: the persistent kernel
     (gemm_sk256_kernel) cuts the last round's tiles along K into 8 / 4 / 2 pieces (272 tiles: 16 left, 289: 33, 361: 105;
     K = 264 -> 10 K-steps: pieces of one or two steps), partners exchange fp32 partial tiles through the workspace. Odd sizes put
-    edge tiles into the tail and run the pad copies of odd-length rows. Same bound as test_addmm_big_tiles; also equal
+    edge tiles into the tail and run the pad copies of odd-length rows; 2 x 145 and 145 x 2 tiles walk short and
+    single-row bands of the tile order. Same bound as test_addmm_big_tiles; also equal
     to the plain-grid kernel's result up to one rounding of the output type (the pieces are summed in a different order)."""
     import os
     g = torch.Generator().manual_seed(6)
