@@ -378,7 +378,44 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
 
     const T* sp = src + (b * E) * K + k0 + kk;
     const I* ip = index + (b * E) * K + k0 + kk;
-    if (col_ok) {
+    // one element: NaNs never win, and neither does the reduce's identity (+inf for min, -inf for max): the sequential loop
+    // replaces on a strict improvement only, so a group fed nothing else stays empty — as in segment.hip
+    auto feed = [&](int64_t e, int64_t dst, const T* vp) {
+        const int64_t d = dst - n_lo;
+        const float v = Elem<T>::load(vp);
+        if (d < 0 || d >= nloc || v != v || v == (IS_MIN ? __builtin_huge_valf() : -__builtin_huge_valf())) return;
+        const CellT pos = (CellT)(e + 1);
+        const CellT lo = IS_MIN ? pos : (CellT)(~pos & LO_MASK);
+        const CellT w = (CellT)((order_image<CellT, T>(vp, v) << HB) | lo);
+        if (IS_MIN) atomicMin(&cell[(int)d * tc + kk], w); else atomicMax(&cell[(int)d * tc + kk], w);
+    };
+    // K == 1 (the last-dim scatter, and the transposed dim-0 route of the big shapes): a lane takes FOUR consecutive elements
+    // per load — 16 B of a 4-byte src, 16 / 32 B of index — so a workgroup has 4 x the bytes in flight (one 1024-thread
+    // workgroup per CU streams a 300 KB row at the latency-bound rate otherwise: (38000)^2 scatter_max)
+    constexpr int VU = 4;
+    struct alignas(sizeof(T) * 4) TV { T v[4]; };
+    struct alignas(sizeof(I) * 4 > 16 ? 16 : sizeof(I) * 4) IV { I v[4]; };
+    const bool vec4 = K == 1 && (E & 3) == 0 && sizeof(T) == 4 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)index % 16) == 0;
+    if (vec4) {
+        for (int64_t e0 = (int64_t)er * 4; e0 < E; e0 += (int64_t)rpi * 4 * VU) {
+            TV vt4[VU];
+            IV nl4[VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int64_t e = e0 + (int64_t)u * rpi * 4;
+                const int64_t ec = e < E ? e : E - 4;
+                vt4[u] = *reinterpret_cast<const TV*>(sp + ec);
+                nl4[u] = *reinterpret_cast<const IV*>(ip + ec);
+            }
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int64_t e = e0 + (int64_t)u * rpi * 4;
+                if (e >= E) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) feed(e + j, (int64_t)nl4[u].v[j], &vt4[u].v[j]);
+            }
+        }
+    } else if (col_ok) {
         for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
             int64_t nl[UNR];
             T vt[UNR];
@@ -392,15 +429,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int64_t e = e0 + (int64_t)u * rpi;
-                const int64_t d = nl[u] - n_lo;
-                const float v = Elem<T>::load(&vt[u]);
-                // NaNs never win, and neither does the reduce's identity (+inf for min, -inf for max): the sequential loop
-                // replaces on a strict improvement only, so a group fed nothing else stays empty — as in segment.hip
-                if (e >= E || d < 0 || d >= nloc || v != v || v == (IS_MIN ? __builtin_huge_valf() : -__builtin_huge_valf())) continue;
-                const CellT pos = (CellT)(e + 1);
-                const CellT lo = IS_MIN ? pos : (CellT)(~pos & LO_MASK);
-                const CellT w = (CellT)((order_image<CellT, T>(&vt[u], v) << HB) | lo);
-                if (IS_MIN) atomicMin(&cell[(int)d * tc + kk], w); else atomicMax(&cell[(int)d * tc + kk], w);
+                if (e < E) feed(e, nl[u], &vt[u]);
             }
         }
     }
@@ -416,7 +445,18 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_minmax_kernel(const T
                 c[u] = cell[(r < nloc ? r : nloc - 1) * tc + kk];
                 val[u] = 0.f;
             }
-            if (E > 0) {  // uniform: the eight loads below stay together
+            if constexpr (sizeof(CellT) == 8 && sizeof(T) == 4) {
+                // the fp32 image is the value: undo it instead of a random 4-B read per destination. Only a zero has to be
+                // looked up — +0.0 and -0.0 share an image and the stored bits are the winner's.
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const uint32_t img = (uint32_t)(c[u] >> HB);
+                    const uint32_t bits = (img & 0x80000000u) ? (img & 0x7fffffffu) : ~img;
+                    val[u] = __uint_as_float(bits);
+                    const int64_t e = winner(c[u]);
+                    if (img == 0x80000000u && e >= 0) val[u] = Elem<T>::load(sp + e * K);
+                }
+            } else if (E > 0) {  // uniform: the eight loads below stay together
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int64_t e = winner(c[u]);

@@ -131,26 +131,46 @@ __global__ void reduce_runs_kernel(const T* __restrict__ value, const uint32_t* 
 // ---- dense 2-D transpose through a padded LDS tile (64 x 64 elements, conflict-free column reads) ----
 // O != U: the elements are converted on the way (int64 -> int32 index narrowing / int32 -> int64 arg widening of the
 // dim-0 route of large full-index scatters, ops.py: the tile holds the OUTPUT type).
-template <typename U, typename O = U>
+// TRACK (int64 in only): the largest element read goes to *max_out (atomicMax, one per wave) — torch_scatter's implicit
+// dim_size = index.max() + 1 comes out of the index's own transpose instead of one more pass over it (ops.py).
+template <typename U, typename O = U, bool TRACK = false>
 __global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in, O* __restrict__ out, int64_t R,
-                                                        int64_t C) {
+                                                        int64_t C, long long* __restrict__ max_out = nullptr) {
     __shared__ O tile[64][64 + (sizeof(O) >= 4 ? 1 : 4 / sizeof(O))];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     in += (int64_t)blockIdx.z * R * C;   // batch of independent [R, C] matrices
     out += (int64_t)blockIdx.z * R * C;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    long long seen = -1;
     if (r0 + 64 <= R && c0 + 64 <= C) {   // interior tile: the sixteen loads are issued together, then parked in LDS
         U v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = in[(r0 + ty + 4 * j) * C + c0 + tx];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) tile[ty + 4 * j][tx] = (O)v[j];
+        for (int j = 0; j < 16; ++j) {
+            tile[ty + 4 * j][tx] = (O)v[j];
+            if constexpr (TRACK) seen = (long long)v[j] > seen ? (long long)v[j] : seen;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int64_t r = r0 + ty + 4 * j, c = c0 + tx;
-            if (r < R && c < C) tile[ty + 4 * j][tx] = (O)in[r * C + c];
+            if (r < R && c < C) {
+                const U x = in[r * C + c];
+                tile[ty + 4 * j][tx] = (O)x;
+                if constexpr (TRACK) seen = (long long)x > seen ? (long long)x : seen;
+            }
         }
+    }
+    if constexpr (TRACK) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const long long o = __shfl_xor(seen, d, 64);
+            seen = o > seen ? o : seen;
+        }
+        // a look first: 1.4 M waves adding to ONE address serialise at the memory side (+10 ms at (38000)^2); once the running
+        // maximum is near the top almost no wave has anything to add (a stale look only costs an atomic that changes nothing)
+        if (tx == 0 && seen > __hip_atomic_load(max_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_out, seen);
     }
     __syncthreads();
 #pragma unroll
@@ -305,6 +325,19 @@ extern "C" int gnnops_transpose2d_cvt(const void* in, void* out, int64_t R, int6
     else
         hipLaunchKernelGGL((transpose_kernel<int32_t, int64_t>), grid, dim3(256), 0, (hipStream_t)s, (const int32_t*)in, (int64_t*)out, R, C);
     return gnnops_check_launch("transpose2d_cvt");
+}
+
+extern "C" int gnnops_transpose2d_cvt_max(const void* in, void* out, int64_t R, int64_t C, int64_t* max_out, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(R >= 0 && C >= 0, GNNOPS_EINVAL, "transpose2d_cvt_max: negative size");
+    GNNOPS_REQUIRE(max_out != nullptr, GNNOPS_EINVAL, "transpose2d_cvt_max: null pointer");
+    if (gnnops_memset_async(max_out, 0xff, sizeof(int64_t), (hipStream_t)s) != hipSuccess) return gnnops_check_launch("transpose2d_cvt_max init");
+    if (R * C == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(in && out, GNNOPS_EINVAL, "transpose2d_cvt_max: null pointer");
+    GNNOPS_REQUIRE(gnnops_cdiv(R, 64) < 65536, GNNOPS_EUNSUPPORTED, "transpose2d_cvt_max: too many rows");
+    dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64), 1);
+    hipLaunchKernelGGL((transpose_kernel<int64_t, int32_t, true>), grid, dim3(256), 0, (hipStream_t)s, (const int64_t*)in, (int32_t*)out, R, C,
+                       (long long*)max_out);
+    return gnnops_check_launch("transpose2d_cvt_max");
 }
 
 extern "C" int gnnops_transpose_batched(const void* in, void* out, int64_t batch, int64_t R, int64_t C, int elem_bytes,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "gnnops_scatter1d_sum": (_ci, [_vp, _vp, _vp, _i64, _i64, _ci, _ci, _vp, _sz, _vp]),
     "gnnops_scatter_elementwise_ixa": (_ci, [_vp, _vp, _ci, _vp, _vp, _ci, _i64, _i64, _i64, _i64, _ci, _ci, _ci, _vp, _sz, _vp]),
     "gnnops_transpose2d_cvt": (_ci, [_vp, _vp, _i64, _i64, _ci, _vp]),
+    "gnnops_transpose2d_cvt_max": (_ci, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "gnnops_narrow_index": (_ci, [_vp, _vp, _i64, _ci, _i64, _vp]),
     "gnnops_index_select": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),
     "gnnops_index_select_planned": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp]),

@@ -289,17 +289,27 @@ def index_max(index):
     cold numbers — computes it every time."""
     _require_gpu(index)
     _check_index(index, "index_max")
-    if _plan_cache_enabled and _version_of(index) is not None:
-        hit = _max_cache.get(id(index))
-        if hit is not None and hit[0]() is index and hit[1] == index._version:
-            return hit[2]
+    value = _remembered_index_max(index)
+    if value is None:
         value = _index_max_now(index)
+        _remember_index_max(index, value)
+    return value
+
+
+def _remember_index_max(index, value):
+    if _plan_cache_enabled and _version_of(index) is not None:
         if len(_max_cache) >= _PLAN_CACHE_MAX:
             _max_cache.pop(next(iter(_max_cache)))
         key = id(index)
         _max_cache[key] = (weakref.ref(index, lambda _r, key=key: _max_cache.pop(key, None)), index._version, value)
-        return value
-    return _index_max_now(index)
+
+
+def _remembered_index_max(index):
+    if _plan_cache_enabled and _version_of(index) is not None:
+        hit = _max_cache.get(id(index))
+        if hit is not None and hit[0]() is index and hit[1] == index._version:
+            return hit[2]
+    return None
 
 
 def _index_max_now(index):
@@ -316,6 +326,8 @@ def _index_max_now(index):
 # --------------------------------------------------------------------------------------------------
 _SCATTER1D_MIN_N = 1 << 22     # 1-D min / max over at least this many destinations takes the carried-value form (scatter1d.hip)
 _LDS_STRIP_BYTES = 160 * 1024 - 512   # csrc/scatter_elem.hip LDS_BUDGET: what one workgroup's strip of destinations may take
+_FUSED_MAX_MIN_NUMEL = 1 << 26        # from here on a pass over the index costs more than the extra small read-back that saves it
+_FUSED_MAX_SAMPLE = 1 << 20           # ids looked at to guess whether the destinations will fit an LDS strip
 
 
 def _row_index_of(index, src, dim):
@@ -350,27 +362,42 @@ def _scatter_transposed(src2, full, N, reduce, rcode, dt, L):
     Of the 69 GB that route moved in transposes at (38000)^2, 46 were the int64 index going in and the int64 arg coming out:
     the index is narrowed to int32 INSIDE its transpose and the positions come out of the kernel as int32 rows, widened inside
     the transpose back (gnnops_transpose2d_cvt, gnnops_scatter_elementwise_ixa). Returns out [N, K] (and arg), or None when
-    the kernel does not take the narrowed operands (the caller then takes the int64 route)."""
+    the kernel does not take the narrowed operands (the caller then takes the int64 route). N = None: the size is
+    index.max() + 1, found inside the index's transpose; an int (that size) is returned instead of None when the route does
+    not apply after all."""
     from .sparse import transpose_contiguous
 
     E, K = src2.shape
-    if E >= 2 ** 31 or N >= 2 ** 31:
+    if E >= 2 ** 31 or (N is not None and N >= 2 ** 31):
         return None
     dev = src2.device
     want_arg = rcode in (_lib.MIN, _lib.MAX)
     src_t = transpose_contiguous(src2)                                          # [K, E]
     idx_t = torch.empty((K, E), dtype=torch.int32, device=dev)
+    if N is None:
+        # torch_scatter's implicit dim_size: the index's transpose reads every id anyway and leaves the largest behind — one
+        # host read-back as before, without the extra pass over the index (1.7 of 21.5 ms at (38000, 38000))
+        top = torch.empty(1, dtype=torch.int64, device=dev)
+        with _on(dev):
+            check(L.gnnops_transpose2d_cvt_max(full.data_ptr(), idx_t.data_ptr(), E, K, top.data_ptr(), _stream()), "transpose2d_cvt_max")
+        N = int(top.item()) + 1
+        if N >= 2 ** 31:
+            return N            # the int32 copy is meaningless: the caller takes the int64 route with the size it now knows
+        narrowed = True
+    else:
+        narrowed = False
     out_t = torch.empty((K, N), dtype=src2.dtype, device=dev)
     arg_t = torch.empty((K, N), dtype=torch.int32, device=dev) if want_arg else None
     ws_bytes = L.gnnops_scatter_elementwise_workspace_bytes(K, N, 1, dt, rcode)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
     with _on(dev):
-        check(L.gnnops_transpose2d_cvt(full.data_ptr(), idx_t.data_ptr(), E, K, 0, _stream()), "transpose2d_cvt")
+        if not narrowed:
+            check(L.gnnops_transpose2d_cvt(full.data_ptr(), idx_t.data_ptr(), E, K, 0, _stream()), "transpose2d_cvt")
         rc = L.gnnops_scatter_elementwise_ixa(src_t.data_ptr(), idx_t.data_ptr(), 4, out_t.data_ptr(),
                                               arg_t.data_ptr() if want_arg else None, 4 if want_arg else 8, K, E, 1, N, dt, rcode, 0,
                                               ws.data_ptr(), ws_bytes, _stream())
         if rc == _lib.EUNSUPPORTED:
-            return None
+            return N if narrowed else None
         check(rc, "scatter_elementwise")
         out = transpose_contiguous(out_t)                                       # [N, K]
         if not want_arg:
@@ -427,7 +454,30 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
         elif is_plan:
             N = index.N
         else:
-            N = index_max(index if row_index is None else row_index) + 1 if index.numel() else 0
+            N = None
+            if (row_index is None and B == 1 and K > 1 and E < 2 ** 31 and src.numel() >= _FUSED_MAX_MIN_NUMEL
+                    and index.shape == src.shape and index.is_contiguous() and _remembered_index_max(index) is None):
+                # A big layout-F scatter along dim 0 with an implicit dim_size. If its destinations will not fit an LDS strip
+                # it takes the transposed route below, whose index transpose can find index.max() on the way. Whether they
+                # fit is a question about that same max: the first 2^20 ids answer it (uniform ids: to a part in a million);
+                # a wrong guess costs time, never correctness — both routes are complete for any N.
+                cell = 4 if (reduce in ("sum", "add", "mul") or (reduce in ("min", "max") and src.element_size() == 2 and E < 65535)) else 8
+                guess = _index_max_now(index.view(-1)[:_FUSED_MAX_SAMPLE]) + 1
+                if guess * cell > _LDS_STRIP_BYTES:
+                    res = _scatter_transposed(src.view(E, K), index.view(E, K), None, reduce, rcode, dt, L)
+                    if isinstance(res, int):
+                        N = res                      # route refused after the size was found: carry on with the size
+                        _remember_index_max(index, N - 1)
+                    else:
+                        n_out = (res[0] if isinstance(res, tuple) else res).size(0)
+                        _remember_index_max(index, n_out - 1)
+                        shape = list(src.shape)
+                        shape[dim] = n_out
+                        if isinstance(res, tuple):
+                            return res[0].view(shape), res[1].view(shape)
+                        return res.view(shape)
+            if N is None:
+                N = index_max(index if row_index is None else row_index) + 1 if index.numel() else 0
         if row_index is None and B == 1 and K > 1 and E < 2 ** 31:
             cell = 4 if (reduce in ("sum", "add", "mul") or (reduce in ("min", "max") and src.element_size() == 2 and E < 65535)) else 8
             if N * cell > _LDS_STRIP_BYTES:

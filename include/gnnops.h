@@ -302,6 +302,10 @@ int gnnops_transpose2d(const void* in, void* out, int64_t R, int64_t C, int elem
                        gnnops_stream_t stream);
 /* [R, C] int64 -> [C, R] int32 (mode 0: every value must fit in 31 bits) or [R, C] int32 -> [C, R] int64 (mode 1). */
 int gnnops_transpose2d_cvt(const void* in, void* out, int64_t R, int64_t C, int mode, gnnops_stream_t stream);
+/* mode 0 with the largest element read left in *max_out (-1 for an empty matrix; device memory, written on the stream):
+ * torch_scatter's implicit dim_size = index.max() + 1 from the index's own transpose. Values >= 2^31 make the int32 copy
+ * meaningless — the caller checks *max_out before using it. */
+int gnnops_transpose2d_cvt_max(const void* in, void* out, int64_t R, int64_t C, int64_t* max_out, gnnops_stream_t stream);
 /* batch of independent [R, C] -> [C, R] copies (in / out [batch, R, C] / [batch, C, R]). */
 int gnnops_transpose_batched(const void* in, void* out, int64_t batch, int64_t R, int64_t C, int elem_bytes,
                              gnnops_stream_t stream);

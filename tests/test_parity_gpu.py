@@ -555,6 +555,51 @@ def test_layout_f_dim0_more_destinations_than_an_lds_strip(gnnops, oracle, reduc
     _close(to_np(g3).reshape(N, K), e3, dname, 4, reduce + " 3-D")
 
 
+@pytest.mark.parametrize("reduce", ["max", "min", "sum", "mean"])
+def test_layout_f_dim0_implicit_size_comes_out_of_the_index_transpose(gnnops, oracle, reduce, monkeypatch):
+    """dim_size=None on the transposed route: index.max() is found INSIDE the index's transpose (gnnops_transpose2d_cvt_max)
+    after a look at the first 2^20 ids says the destinations will not fit an LDS strip — no separate pass over the index.
+    Same results as with the size given; the size itself is exact even when the largest id sits in the last row (beyond the
+    ids the guess looked at), and a guess that says "fits" falls back to the ordinary pass. Threshold lowered for the test."""
+    from gnnops import ops
+
+    monkeypatch.setattr(ops, "_FUSED_MAX_MIN_NUMEL", 1)
+    g = torch.Generator().manual_seed(14)
+    E, K, N = 321, 40, 50_000
+    src = (torch.rand(E, K, generator=g) * 2 - 1)
+    idx = torch.randint(0, N - 7, (E, K), generator=g)
+    idx[E - 1, K - 1] = N - 1                                     # the maximum is the very last id
+    idx[:30] = idx[30:60]
+    full_pass = []
+    real_max = ops._index_max_now
+    monkeypatch.setattr(ops, "_index_max_now", lambda i: (full_pass.append(i.numel()), real_max(i))[1])
+    got = gnnops.scatter(src.cuda(), idx.cuda(), 0, reduce=reduce)
+    assert full_pass == [E * K]              # one look at (at most) 2^20 ids — here all of them — and no second pass
+    exp = oracle.scatter(to_np(src), idx.numpy(), dim=0, dim_size=N, reduce=reduce, dtype="f32")
+    ref = gnnops.scatter(src.cuda(), idx.cuda(), 0, dim_size=N, reduce=reduce)
+    if reduce in ("min", "max"):
+        assert got[0].shape == (N, K)
+        assert_bits_equal(to_np(got[0]), exp[0], reduce)
+        assert np.array_equal(got[1].cpu().numpy(), exp[1])
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    else:
+        assert got.shape == (N, K)
+        _close(to_np(got), exp, "f32", 4, reduce)
+    # ids that start small: the guess (from the first 64 ids here) says the destinations fit, the ordinary pass over the whole
+    # index finds the true size, results unchanged
+    monkeypatch.setattr(ops, "_FUSED_MAX_SAMPLE", 64)
+    idx2 = idx.clone()
+    idx2[:2] %= 1000
+    full_pass.clear()
+    got2 = gnnops.scatter(src.cuda(), idx2.cuda(), 0, reduce=reduce)
+    assert full_pass == [64, E * K]
+    exp2 = oracle.scatter(to_np(src), idx2.numpy(), dim=0, dim_size=N, reduce=reduce, dtype="f32")
+    g2 = got2[0] if isinstance(got2, tuple) else got2
+    e2 = exp2[0] if isinstance(exp2, tuple) else exp2
+    assert g2.shape == (N, K)
+    _close(to_np(g2), e2, "f32", 4, reduce + " (guess says fits)")
+
+
 def test_implicit_dim_size_is_remembered_per_index_tensor(gnnops, oracle, monkeypatch):
     """torch_scatter's dim_size=None means int(index.max()) + 1: a full read of the index and a host round trip per call. With
     the plan cache on it is remembered per index tensor object + version (an in-place write recomputes it); with the cache off

@@ -9,7 +9,12 @@ import gnnops, torch_scatter, torch_sparse
 dev = "cuda"
 gnnops.set_plan_cache(False)
 
+ONLY = sys.argv[1:]   # substrings: run only the lines whose name holds one of them
+
+
 def timed(name, a100_s, build, run, check=None, iters=2):
+    if ONLY and not any(o in name for o in ONLY):
+        return
     try:
         args = build()
         torch.cuda.synchronize()
