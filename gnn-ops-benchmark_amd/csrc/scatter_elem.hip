@@ -210,7 +210,50 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
 
     const T* sp = src + (b * E) * K + k0 + kk;
     const I* ip = index + (b * E) * K + k0 + kk;
-    if (col_ok) {
+    // one element into its LDS cell (dl = destination relative to this chunk; past the end / another chunk's: dropped)
+    auto feed = [&](int64_t dl, float val) {
+        if (dl < 0 || dl >= nloc) return;
+        const int a = (int)dl * tc + kk;
+        // the float add goes through a read + compare-and-swap on LDS, not ds_add_f32: measured on gfx950, the
+        // float LDS atomic costs ~170 LDS-array cycles per wave-instruction (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS)
+        // and bounded this kernel; the integer CAS path does not
+        if constexpr (R == GNNOPS_SUM) {
+            atomic_update(&acc[a], val, [](float x, float y) { return x + y; });
+        } else if constexpr (R == GNNOPS_MEAN) {
+            atomic_update(&acc[a], val, [](float x, float y) { return x + y; });
+            atomicAdd(&aux[a], 1);
+        } else if constexpr (R == GNNOPS_MUL) {
+            atomic_update(&acc[a], val, [](float x, float y) { return x * y; });
+        } else if constexpr (R == GNNOPS_MIN) {
+            atomic_update(&acc[a], val, [](float x, float y) { return y < x ? y : x; });
+        } else {
+            atomic_update(&acc[a], val, [](float x, float y) { return y > x ? y : x; });
+        }
+    };
+    // K == 1, 4-byte elements: four consecutive elements per lane and load (see scatter_lds_minmax_kernel)
+    struct alignas(sizeof(T) * 4) TV { T v[4]; };
+    struct alignas(sizeof(I) * 4 > 16 ? 16 : sizeof(I) * 4) IV { I v[4]; };
+    const bool vec4 = !IS_ARG && K == 1 && (E & 3) == 0 && sizeof(T) == 4 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)index % 16) == 0;
+    if (vec4) {
+        constexpr int VU = 4;
+        for (int64_t e0 = (int64_t)er * 4; e0 < E; e0 += (int64_t)rpi * 4 * VU) {
+            TV vt4[VU];
+            IV nl4[VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int64_t e = e0 + (int64_t)u * rpi * 4;
+                const int64_t ec = e < E ? e : E - 4;
+                vt4[u] = *reinterpret_cast<const TV*>(sp + ec);
+                nl4[u] = *reinterpret_cast<const IV*>(ip + ec);
+            }
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                if (e0 + (int64_t)u * rpi * 4 >= E) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) feed((int64_t)nl4[u].v[j] - n_lo, Elem<T>::load(&vt4[u].v[j]));
+            }
+        }
+    } else if (col_ok) {
         for (int64_t e0 = er; e0 < E; e0 += (int64_t)rpi * UNR) {
             int64_t nl[UNR];
             float v[UNR];
@@ -226,25 +269,7 @@ __global__ __launch_bounds__(LDS_THREADS) void scatter_lds_kernel(const T* __res
 #pragma unroll
             for (int u = 0; u < UNR; ++u) nl[u] = (e0 + (int64_t)u * rpi < E) ? nl[u] - n_lo : -1;
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                if (nl[u] < 0 || nl[u] >= nloc) continue;  // past the end, or another chunk's destination
-                const int a = (int)nl[u] * tc + kk;
-                // the float add goes through a read + compare-and-swap on LDS, not ds_add_f32: measured on gfx950, the
-                // float LDS atomic costs ~170 LDS-array cycles per wave-instruction (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS)
-                // and bounded this kernel; the integer CAS path does not
-                if constexpr (R == GNNOPS_SUM) {
-                    atomic_update(&acc[a], v[u], [](float x, float y) { return x + y; });
-                } else if constexpr (R == GNNOPS_MEAN) {
-                    atomic_update(&acc[a], v[u], [](float x, float y) { return x + y; });
-                    atomicAdd(&aux[a], 1);
-                } else if constexpr (R == GNNOPS_MUL) {
-                    atomic_update(&acc[a], v[u], [](float x, float y) { return x * y; });
-                } else if constexpr (R == GNNOPS_MIN) {
-                    atomic_update(&acc[a], v[u], [](float x, float y) { return y < x ? y : x; });
-                } else {
-                    atomic_update(&acc[a], v[u], [](float x, float y) { return y > x ? y : x; });
-                }
-            }
+            for (int u = 0; u < UNR; ++u) feed(nl[u], v[u]);
         }
     }
     __syncthreads();
