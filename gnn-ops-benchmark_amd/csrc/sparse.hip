@@ -9,6 +9,7 @@
 // data dependent: outputs are sized nnz and the count is left in device memory for the caller.
 // All phases are HBM-bound index work (8-16 B per entry per pass).
 #include "common.h"
+#include <stdlib.h>
 #include "sort_engine.h"
 
 namespace {
@@ -177,6 +178,107 @@ __global__ __launch_bounds__(256) void transpose_kernel(const U* __restrict__ in
     for (int j = 0; j < 16; ++j) {
         const int64_t c = c0 + ty + 4 * j, r = r0 + tx;
         if (r < R && c < C) out[c * R + r] = tile[tx][ty + 4 * j];
+    }
+}
+
+// 2-byte elements (the reference's dense fp16 transpose, benchmark_sparse_transpose.py:13-16): with one element per lane a
+// wave moves 128 B per instruction. Here a lane moves PAIRS both ways — 128 x 128 tiles, 256-B row pieces in and out, the
+// halves of two input rows recombined on the way out. Rows of odd length start 2 bytes off a dword: the 4-B accesses are
+// declared 2-byte aligned (one dword access each in hardware).
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t R,
+                                                          int64_t C) {
+    __shared__ uint32_t tile[128][65];   // [input row][input column pair]
+    const int64_t r0 = (int64_t)blockIdx.y * 128, c0 = (int64_t)blockIdx.x * 128;
+    in += (int64_t)blockIdx.z * R * C;
+    out += (int64_t)blockIdx.z * R * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool interior = r0 + 128 <= R && c0 + 128 <= C;
+    if (interior) {
+        uint32_t v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = *reinterpret_cast<const u32_a2*>(in + (r0 + wave + 4 * j) * C + c0 + 2 * lane);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) tile[wave + 4 * j][lane] = v[j];
+    } else {
+#pragma unroll 4
+        for (int j = 0; j < 32; ++j) {
+            const int64_t r = r0 + wave + 4 * j, c = c0 + 2 * lane;
+            uint32_t lo = 0, hi = 0;
+            if (r < R && c < C) lo = in[r * C + c];
+            if (r < R && c + 1 < C) hi = in[r * C + c + 1];
+            tile[wave + 4 * j][lane] = lo | (hi << 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        const int c = wave + 4 * j;                      // output row = input column c0 + c; this lane: input rows 2 lane, 2 lane + 1
+        const uint32_t a = tile[2 * lane][c >> 1], b = tile[2 * lane + 1][c >> 1];
+        const uint32_t w = (c & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+        const int64_t oc = c0 + c, orow = r0 + 2 * lane;
+        if (interior) {
+            *reinterpret_cast<u32_a2*>(out + oc * R + orow) = w;
+        } else if (oc < C) {
+            if (orow < R) out[oc * R + orow] = (uint16_t)w;
+            if (orow + 1 < R) out[oc * R + orow + 1] = (uint16_t)(w >> 16);
+        }
+    }
+}
+
+// 4-byte elements, wider pieces: a lane loads LW and stores SW consecutive elements (8 B when 2): tiles of 64 SW rows x 64 LW
+// columns, row pieces of 256 LW bytes in and 256 SW bytes out. Rows need only 4-byte alignment (odd lengths).
+struct __attribute__((aligned(4))) u32x2_a4 { uint32_t x, y; };
+template <int LW, int SW>
+__global__ __launch_bounds__(256) void transpose32_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t R,
+                                                          int64_t C) {
+    constexpr int TR = 64 * SW, TC = 64 * LW;
+    __shared__ uint32_t tile[TR][TC + 1];
+    const int64_t r0 = (int64_t)blockIdx.y * TR, c0 = (int64_t)blockIdx.x * TC;
+    in += (int64_t)blockIdx.z * R * C;
+    out += (int64_t)blockIdx.z * R * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool interior = r0 + TR <= R && c0 + TC <= C;
+    if (interior) {
+        uint32_t v[TR / 4][LW];
+#pragma unroll
+        for (int j = 0; j < TR / 4; ++j) {
+            const uint32_t* p = in + (r0 + wave + 4 * j) * C + c0 + LW * lane;
+            if constexpr (LW == 2) {
+                const u32x2_a4 t = *reinterpret_cast<const u32x2_a4*>(p);
+                v[j][0] = t.x; v[j][1] = t.y;
+            } else {
+                v[j][0] = *p;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TR / 4; ++j)
+#pragma unroll
+            for (int w = 0; w < LW; ++w) tile[wave + 4 * j][LW * lane + w] = v[j][w];
+    } else {
+        for (int j = 0; j < TR / 4; ++j)
+            for (int w = 0; w < LW; ++w) {
+                const int64_t r = r0 + wave + 4 * j, c = c0 + LW * lane + w;
+                if (r < R && c < C) tile[wave + 4 * j][LW * lane + w] = in[r * C + c];
+            }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int j = 0; j < TC / 4; ++j) {
+        const int c = wave + 4 * j;
+        const int64_t oc = c0 + c, orow = r0 + SW * lane;
+        if (interior) {
+            if constexpr (SW == 2) {
+                u32x2_a4 t;
+                t.x = tile[2 * lane][c]; t.y = tile[2 * lane + 1][c];
+                *reinterpret_cast<u32x2_a4*>(out + oc * R + orow) = t;
+            } else {
+                out[oc * R + orow] = tile[lane][c];
+            }
+        } else if (oc < C) {
+            for (int w = 0; w < SW; ++w)
+                if (orow + w < R) out[oc * R + orow + w] = tile[SW * lane + w][c];
+        }
     }
 }
 
@@ -361,9 +463,25 @@ extern "C" int gnnops_transpose_batched(const void* in, void* out, int64_t batch
     dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64), (unsigned)batch);
     if (elem_bytes == 1)
         hipLaunchKernelGGL((transpose_kernel<uint8_t>), grid, dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, R, C);
+    else if (elem_bytes == 2 && R >= 128 && C >= 128 && gnnops_cdiv(R, 128) < 65536)
+        hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)gnnops_cdiv(C, 128), (unsigned)gnnops_cdiv(R, 128), (unsigned)batch), dim3(256), 0,
+                           stream, (const uint16_t*)in, (uint16_t*)out, R, C);
     else if (elem_bytes == 2)
         hipLaunchKernelGGL((transpose_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, R, C);
-    else if (elem_bytes == 4)
+    else if (elem_bytes == 4 && R >= 128 && C >= 128 && gnnops_cdiv(R, 128) < 65536 && !(getenv("GNNOPS_T32") && getenv("GNNOPS_T32")[0] == '0')) {
+        // A/B (tools/time_transpose.py): 0 = one element per lane, 1 = 8-B loads, 2 = 8-B stores, 3 = both. Measured: 8-B loads win
+        // up to (8192)^2 (111 -> 90 us at (7071)^2), 8-B stores from there on ((28200)^2 1650 -> 1309 us, (38000)^2 2892 -> 2516)
+        const char* m = getenv("GNNOPS_T32");
+        const int mode = m ? atoi(m) : (R * C >= ((int64_t)1 << 27) ? 2 : 1);
+        const uint32_t* i = (const uint32_t*)in;
+        uint32_t* o = (uint32_t*)out;
+        if (mode == 1)
+            hipLaunchKernelGGL((transpose32_kernel<2, 1>), dim3((unsigned)gnnops_cdiv(C, 128), (unsigned)gnnops_cdiv(R, 64), (unsigned)batch), dim3(256), 0, stream, i, o, R, C);
+        else if (mode == 2)
+            hipLaunchKernelGGL((transpose32_kernel<1, 2>), dim3((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 128), (unsigned)batch), dim3(256), 0, stream, i, o, R, C);
+        else
+            hipLaunchKernelGGL((transpose32_kernel<2, 2>), dim3((unsigned)gnnops_cdiv(C, 128), (unsigned)gnnops_cdiv(R, 128), (unsigned)batch), dim3(256), 0, stream, i, o, R, C);
+    } else if (elem_bytes == 4)
         hipLaunchKernelGGL((transpose_kernel<uint32_t>), grid, dim3(256), 0, stream, (const uint32_t*)in, (uint32_t*)out, R, C);
     else
         hipLaunchKernelGGL((transpose_kernel<uint64_t>), grid, dim3(256), 0, stream, (const uint64_t*)in, (uint64_t*)out, R, C);

@@ -160,12 +160,28 @@ def test_coalesce_and_transpose(gnnops, oracle, m, n, nnz, dup, dname):
 
 
 @pytest.mark.parametrize("dname", ["f16", "f32"])
-@pytest.mark.parametrize("R,C", [(2000, 2000), (7071, 333), (65, 129), (1, 500), (64, 64)])
+@pytest.mark.parametrize("R,C", [(2000, 2000), (7071, 333), (65, 129), (1, 500), (64, 64), (128, 128), (129, 131), (1001, 257),
+                                 (257, 1001), (3001, 2999), (128, 4097)])
 def test_dense_transpose(gnnops, oracle, R, C, dname):
     g = torch.Generator().manual_seed(8)
     x = torch.rand(R, C, generator=g).to(TORCH_DT[dname])
     got = gnnops.transpose_contiguous(x.cuda())
     assert_bits_equal(to_np(got), oracle.transpose_dense(to_np(x)), "transpose")
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2", "3"])
+def test_dense_transpose_4_byte_forms(gnnops, mode, monkeypatch):
+    """csrc/sparse.hip transpose32_kernel: one element per lane, 8-B loads (128-column tiles), 8-B stores (128-row tiles) or both;
+    the library picks by size, GNNOPS_T32 forces one. Odd row lengths (4-byte aligned 8-B accesses), edge tiles on both sides,
+    a batch of matrices through the 3-D entry."""
+    monkeypatch.setenv("GNNOPS_T32", mode)
+    g = torch.Generator().manual_seed(9)
+    for R, C in ((1001, 777), (128, 128), (4097, 129), (300, 5001)):
+        x = torch.randint(-2 ** 31, 2 ** 31 - 1, (R, C), generator=g, dtype=torch.int64).to(torch.int32)
+        assert torch.equal(gnnops.transpose_contiguous(x.cuda()).cpu(), x.t().contiguous()), (R, C)
+    from gnnops import sparse
+    x3 = torch.rand(5, 257, 131, generator=g)
+    assert torch.equal(sparse._transpose_batched(x3.cuda()).cpu(), x3.transpose(1, 2).contiguous())
 
 
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
