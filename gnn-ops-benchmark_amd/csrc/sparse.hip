@@ -282,6 +282,59 @@ __global__ __launch_bounds__(256) void transpose32_kernel(const uint32_t* __rest
     }
 }
 
+// int64 -> int32 with 8-B pieces BOTH ways: a lane loads one int64 and stores two int32 of consecutive input rows (128-row
+// tiles, 512-B row pieces in and out) — the index narrowing of the dim-0 route at its own size ((38000)^2: 17.4 GB).
+template <bool TRACK>
+__global__ __launch_bounds__(256) void transpose_narrow_kernel(const int64_t* __restrict__ in, int32_t* __restrict__ out, int64_t R,
+                                                               int64_t C, long long* __restrict__ max_out) {
+    __shared__ int32_t tile[128][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 128, c0 = (int64_t)blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool interior = r0 + 128 <= R && c0 + 64 <= C;
+    long long seen = -1;
+    if (interior) {
+        int64_t v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = in[(r0 + wave + 4 * j) * C + c0 + lane];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            tile[wave + 4 * j][lane] = (int32_t)v[j];
+            if constexpr (TRACK) seen = v[j] > seen ? v[j] : seen;
+        }
+    } else {
+        for (int j = 0; j < 32; ++j) {
+            const int64_t r = r0 + wave + 4 * j, c = c0 + lane;
+            if (r < R && c < C) {
+                const int64_t x = in[r * C + c];
+                tile[wave + 4 * j][lane] = (int32_t)x;
+                if constexpr (TRACK) seen = x > seen ? x : seen;
+            }
+        }
+    }
+    if constexpr (TRACK) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const long long o = __shfl_xor(seen, d, 64);
+            seen = o > seen ? o : seen;
+        }
+        if (lane == 0 && seen > __hip_atomic_load(max_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_out, seen);
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int j = 0; j < 16; ++j) {
+        const int c = wave + 4 * j;
+        const int64_t oc = c0 + c, orow = r0 + 2 * lane;
+        if (interior) {
+            u32x2_a4 t;
+            t.x = (uint32_t)tile[2 * lane][c]; t.y = (uint32_t)tile[2 * lane + 1][c];
+            *reinterpret_cast<u32x2_a4*>(out + oc * R + orow) = t;
+        } else if (oc < C) {
+            if (orow < R) out[oc * R + orow] = tile[2 * lane][c];
+            if (orow + 1 < R) out[oc * R + orow + 1] = tile[2 * lane + 1][c];
+        }
+    }
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int grid_for(int64_t n) { return gnnops_grid_cap(gnnops_cdiv(n, 256), 256 * 16); }
 
@@ -422,7 +475,10 @@ extern "C" int gnnops_transpose2d_cvt(const void* in, void* out, int64_t R, int6
     GNNOPS_REQUIRE(in && out, GNNOPS_EINVAL, "transpose2d_cvt: null pointer");
     GNNOPS_REQUIRE(gnnops_cdiv(R, 64) < 65536, GNNOPS_EUNSUPPORTED, "transpose2d_cvt: too many rows");
     dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64), 1);
-    if (mode == 0)
+    if (mode == 0 && R >= 128 && gnnops_cdiv(R, 128) < 65536)
+        hipLaunchKernelGGL((transpose_narrow_kernel<false>), dim3((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 128), 1), dim3(256), 0,
+                           (hipStream_t)s, (const int64_t*)in, (int32_t*)out, R, C, (long long*)nullptr);
+    else if (mode == 0)
         hipLaunchKernelGGL((transpose_kernel<int64_t, int32_t>), grid, dim3(256), 0, (hipStream_t)s, (const int64_t*)in, (int32_t*)out, R, C);
     else
         hipLaunchKernelGGL((transpose_kernel<int32_t, int64_t>), grid, dim3(256), 0, (hipStream_t)s, (const int32_t*)in, (int64_t*)out, R, C);
@@ -437,8 +493,12 @@ extern "C" int gnnops_transpose2d_cvt_max(const void* in, void* out, int64_t R, 
     GNNOPS_REQUIRE(in && out, GNNOPS_EINVAL, "transpose2d_cvt_max: null pointer");
     GNNOPS_REQUIRE(gnnops_cdiv(R, 64) < 65536, GNNOPS_EUNSUPPORTED, "transpose2d_cvt_max: too many rows");
     dim3 grid((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 64), 1);
-    hipLaunchKernelGGL((transpose_kernel<int64_t, int32_t, true>), grid, dim3(256), 0, (hipStream_t)s, (const int64_t*)in, (int32_t*)out, R, C,
-                       (long long*)max_out);
+    if (R >= 128)
+        hipLaunchKernelGGL((transpose_narrow_kernel<true>), dim3((unsigned)gnnops_cdiv(C, 64), (unsigned)gnnops_cdiv(R, 128), 1), dim3(256), 0,
+                           (hipStream_t)s, (const int64_t*)in, (int32_t*)out, R, C, (long long*)max_out);
+    else
+        hipLaunchKernelGGL((transpose_kernel<int64_t, int32_t, true>), grid, dim3(256), 0, (hipStream_t)s, (const int64_t*)in, (int32_t*)out, R, C,
+                           (long long*)max_out);
     return gnnops_check_launch("transpose2d_cvt_max");
 }
 

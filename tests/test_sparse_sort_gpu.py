@@ -169,6 +169,35 @@ def test_dense_transpose(gnnops, oracle, R, C, dname):
     assert_bits_equal(to_np(got), oracle.transpose_dense(to_np(x)), "transpose")
 
 
+@pytest.mark.parametrize("R,C", [(1000, 300), (128, 64), (127, 500), (4100, 129), (257, 63)])
+def test_converting_transposes(gnnops, R, C):
+    """gnnops_transpose2d_cvt (int64 -> int32 and back) and gnnops_transpose2d_cvt_max (the same with the largest id left on the
+    device): interior and edge tiles of the 128-row narrowing kernel, the 64 x 64 fallback below 128 rows, negative ids through
+    the widening, the maximum wherever it sits."""
+    from gnnops import _lib
+    from gnnops.ops import _stream
+
+    L = _lib.load()
+    g = torch.Generator().manual_seed(R * 7 + C)
+    x = torch.randint(0, 2 ** 31 - 1, (R, C), generator=g, dtype=torch.int64)
+    for where in ((0, 0), (R - 1, C - 1), (R // 2, C // 3)):
+        x[where] = 2 ** 31 - 1 - where[0]
+        d = x.cuda()
+        n32 = torch.empty((C, R), dtype=torch.int32, device="cuda")
+        top = torch.empty(1, dtype=torch.int64, device="cuda")
+        assert L.gnnops_transpose2d_cvt_max(d.data_ptr(), n32.data_ptr(), R, C, top.data_ptr(), _stream()) == 0
+        assert int(top.item()) == int(x.max())
+        assert torch.equal(n32.cpu(), x.t().contiguous().to(torch.int32))
+        n32b = torch.empty_like(n32)
+        assert L.gnnops_transpose2d_cvt(d.data_ptr(), n32b.data_ptr(), R, C, 0, _stream()) == 0
+        assert torch.equal(n32b, n32)
+        x[where] = 5
+    y = torch.randint(-2 ** 31, 2 ** 31 - 1, (R, C), generator=g, dtype=torch.int64).to(torch.int32)
+    w64 = torch.empty((C, R), dtype=torch.int64, device="cuda")
+    assert L.gnnops_transpose2d_cvt(y.cuda().data_ptr(), w64.data_ptr(), R, C, 1, _stream()) == 0
+    assert torch.equal(w64.cpu(), y.t().contiguous().to(torch.int64))
+
+
 @pytest.mark.parametrize("mode", ["0", "1", "2", "3"])
 def test_dense_transpose_4_byte_forms(gnnops, mode, monkeypatch):
     """csrc/sparse.hip transpose32_kernel: one element per lane, 8-B loads (128-column tiles), 8-B stores (128-row tiles) or both;
