@@ -10,6 +10,7 @@
 // deterministic — ties go to the smaller index, neighbour lists come out in the package's order (knn: ascending distance;
 // radius: ascending candidate index, first max_num_neighbors).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -99,6 +100,60 @@ __global__ __launch_bounds__(256) void knn_kernel(const T* __restrict__ x, const
                 break;
             }
         }
+    }
+}
+
+// ---- knn, k <= 64: ONE pass over the candidates. The wave keeps the best 64 (distance, index) keys seen so far SORTED
+// ACROSS ITS LANES (lane j holds the j-th smallest); a batch of 64 candidates is compared with the k-th key in one go and
+// the few that beat it are inserted one by one (rank by ballot, shift by one lane). A uniform stream of n candidates makes
+// about k (1 + ln(n / k)) insertions, so a query costs n / 64 distance evaluations per lane instead of k n / 64: the k rounds of
+// knn_kernel above compute every distance k times. Keys are strictly ordered (distance image, then index), so the result is
+// the brute-force one: nearest first, ties to the smaller index, NaN distances never chosen.
+__device__ inline uint32_t knn_order(float v) {
+    uint32_t u = __float_as_uint(v);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline uint64_t shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ inline uint64_t shfl_up_u64(uint64_t v) {
+    const uint32_t lo = __shfl_up((uint32_t)v, 1), hi = __shfl_up((uint32_t)(v >> 32), 1);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename T, bool COSINE>
+__global__ __launch_bounds__(256) void knn_topk_kernel(const T* __restrict__ x, const T* __restrict__ y, const int64_t* __restrict__ ptr_x,
+                                                       const int64_t* __restrict__ ptr_y, int B, int64_t Ny, int D, int k,
+                                                       int64_t* __restrict__ col) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr uint64_t NONE = ~(uint64_t)0;
+    for (int64_t qy = wave0; qy < Ny; qy += nwaves) {
+        const int b = segment_of(ptr_y, B, qy);
+        const int64_t xb = ptr_x[b], xe = ptr_x[b + 1];
+        const T* yq = y + qy * D;
+        uint64_t mine = NONE, kth = NONE;
+        for (int64_t base = xb; base < xe; base += 64) {
+            const int64_t i = base + lane;
+            uint64_t key = NONE;
+            if (i < xe) {
+                const float d = COSINE ? cos_dist<T>(x + i * D, yq, D) : dist2<T>(x + i * D, yq, D);
+                if (d == d) key = ((uint64_t)knn_order(d) << 32) | (uint32_t)(i - xb);
+            }
+            uint64_t todo = __ballot(key < kth);
+            while (todo) {
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint64_t c = shfl_u64(key, src);
+                if (!(c < kth)) continue;                          // the bound has tightened since the ballot
+                const int p = __popcll(__ballot(mine < c));       // sorted: the smaller keys are lanes 0 .. p-1
+                const uint64_t up = shfl_up_u64(mine);
+                mine = lane < p ? mine : (lane == p ? c : up);
+                kth = shfl_u64(mine, k - 1);
+            }
+        }
+        if (lane < k) col[qy * k + lane] = mine == NONE ? (int64_t)-1 : xb + (int64_t)(uint32_t)mine;
     }
 }
 
@@ -308,6 +363,17 @@ extern "C" int gnnops_knn(const void* x, const void* y, const int64_t* ptr_x, co
     if (Ny == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(x && y && ptr_x && ptr_y && col, GNNOPS_EINVAL, "knn: null pointer");
     const int grid = gnnops_grid_cap(gnnops_cdiv(Ny, 4), 256 * 32);
+    const char* kf = getenv("GNNOPS_KNN_ROUNDS");   // A/B (tools/time_knn.py): 1 = the k-round kernel for every k
+    if (k <= 64 && !(kf && kf[0] == '1')) {
+        if (cosine) {
+            GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((knn_topk_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y,
+                                                      ptr_x, ptr_y, (int)batches, Ny, D, k, col), "knn")
+        } else {
+            GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((knn_topk_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y,
+                                                      ptr_x, ptr_y, (int)batches, Ny, D, k, col), "knn")
+        }
+        return gnnops_check_launch("knn");
+    }
     if (cosine) {
         GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((knn_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y, ptr_x,
                                                   ptr_y, (int)batches, Ny, D, k, col), "knn")

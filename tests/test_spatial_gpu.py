@@ -153,6 +153,32 @@ def test_knn_fewer_candidates_than_k_and_exact_ties():
     assert got.cpu().tolist() == [[0, 0, 1], [0, 1, 3]]
 
 
+@pytest.mark.parametrize("k", [1, 16, 64, 70])
+@pytest.mark.parametrize("cosine", [False, True])
+def test_knn_one_pass_equals_k_rounds(k, cosine, monkeypatch):
+    """k <= 64 takes the one-pass kernel (the wave keeps its best 64 keys sorted across lanes; csrc/cluster.hip knn_topk_kernel),
+    larger k the k-round kernel; GNNOPS_KNN_ROUNDS=1 forces the latter. Same pairs in the same order on a cloud with many
+    exact ties (points on a coarse lattice, duplicated points), ragged batches, a batch with fewer than k points, and a point
+    whose coordinates are NaN (never a neighbour)."""
+    from torch_cluster import knn
+
+    g = torch.Generator().manual_seed(40 + k)
+    x = torch.randint(0, 6, (5000, 3), generator=g).float() / 4 + 0.25      # lattice: lots of equal distances
+    x[100:140] = x[60:100]
+    x[777] = float("nan")
+    bx = torch.sort(torch.randint(0, 3, (5000,), generator=g)).values
+    bx[-9:] = 3                                                              # batch 3: nine points
+    y = torch.randint(0, 6, (700, 3), generator=g).float() / 4 + 0.3
+    by = torch.sort(torch.randint(0, 4, (700,), generator=g)).values
+    got = knn(x.cuda(), y.cuda(), k, bx.cuda(), by.cuda(), cosine=cosine)
+    monkeypatch.setenv("GNNOPS_KNN_ROUNDS", "1")
+    ref = knn(x.cuda(), y.cuda(), k, bx.cuda(), by.cuda(), cosine=cosine)
+    assert torch.equal(got, ref)
+    assert not bool((got[1] == 777).any())
+    per_query = torch.bincount(got[0].cpu(), minlength=700)
+    assert int(per_query[by == 3].max()) == min(k, 9)
+
+
 @pytest.mark.parametrize("batches", [1, 4])
 def test_radius_and_radius_graph(ora, batches):
     from torch_cluster import radius, radius_graph
