@@ -157,6 +157,154 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const T* __restrict__ x, 
     }
 }
 
+// ---- knn through a uniform grid (one cloud, Euclidean, D <= 3, fp32, k <= 64) ------------------------------------------------
+// torch_cluster's GPU knn is exhaustive (and so are the two kernels above); its CPU path uses a tree. Here: the points are
+// binned into G^D cells of their bounding box (gnnops_knn_grid_cells), sorted by cell with the plan builder (cell = "destination":
+// rowptr = first point of every cell, perm = points in cell order), and a query walks the cells around its own in shells of
+// growing Chebyshev radius s — a row of cells along x is one contiguous range of perm — feeding the same wave-sorted best-64
+// list. It stops when the k-th distance is below the distance to the nearest face of the (2 s + 1)^D block that is not the
+// grid's own edge (less a margin for points the float cell arithmetic put one cell off), or when the block is the whole grid.
+// Same distances, same keys: the pairs are those of the exhaustive kernels, ties and all.
+struct KnnGrid {
+    float lo[3], h[3];   // box origin and cell size per axis (h = 0: the axis is flat, one cell)
+    int g[3];            // cells per axis (1 for axes beyond D)
+};
+
+__global__ void knn_bbox_kernel(const float* __restrict__ x, int64_t n, int D, unsigned* __restrict__ box) {
+    // box[0..2] = min image, box[3..5] = max image per axis (knn_order images: unsigned order == float order); non-finite skipped
+    float lo[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
+    float hi[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int d = 0; d < D; ++d) {
+            const float v = x[i * D + d];
+            if (v - v == 0.f) { lo[d] = v < lo[d] ? v : lo[d]; hi[d] = v > hi[d] ? v : hi[d]; }
+        }
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float a = __shfl_xor(lo[d], o), b = __shfl_xor(hi[d], o);
+            lo[d] = a < lo[d] ? a : lo[d];
+            hi[d] = b > hi[d] ? b : hi[d];
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (lo[d] <= hi[d]) {
+                atomicMin(box + d, knn_order(lo[d]));
+                atomicMax(box + 3 + d, knn_order(hi[d]));
+            }
+        }
+    }
+}
+
+__device__ inline float knn_unorder(uint32_t img) { return __uint_as_float((img & 0x80000000u) ? (img & 0x7fffffffu) : ~img); }
+
+__device__ inline KnnGrid knn_grid_of(const unsigned* __restrict__ box, int D, int G) {
+    KnnGrid g;
+    for (int d = 0; d < 3; ++d) {
+        g.lo[d] = 0.f; g.h[d] = 0.f; g.g[d] = 1;
+        if (d < D) {
+            const float lo = knn_unorder(box[d]), hi = knn_unorder(box[3 + d]);
+            if (lo <= hi) {       // at least one finite coordinate on this axis
+                g.lo[d] = lo;
+                g.h[d] = (hi - lo) / (float)G;
+                g.g[d] = g.h[d] > 0.f ? G : 1;
+            }
+        }
+    }
+    return g;
+}
+__device__ inline int knn_cell_of(const KnnGrid& g, int d, float v) {
+    if (g.g[d] == 1) return 0;
+    const float t = (v - g.lo[d]) / g.h[d];
+    if (!(t >= 0.f)) return 0;                     // below the box, or NaN
+    const int c = t >= (float)g.g[d] ? g.g[d] - 1 : (int)t;
+    return c;
+}
+
+__global__ void knn_cells_kernel(const float* __restrict__ x, int64_t n, int D, int G, const unsigned* __restrict__ box,
+                                 int64_t* __restrict__ cell) {
+    const KnnGrid g = knn_grid_of(box, D, G);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int c[3] = {0, 0, 0};
+        for (int d = 0; d < D; ++d) c[d] = knn_cell_of(g, d, x[i * D + d]);
+        cell[i] = ((int64_t)c[2] * g.g[1] + c[1]) * g.g[0] + c[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t Ny, int D, int k, int G,
+                                                       const unsigned* __restrict__ box, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ perm, int64_t* __restrict__ col) {
+    const KnnGrid g = knn_grid_of(box, D, G);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr uint64_t NONE = ~(uint64_t)0;
+    for (int64_t qy = wave0; qy < Ny; qy += nwaves) {
+        const float* yq = y + qy * D;
+        float q[3] = {0.f, 0.f, 0.f};
+        int cq[3] = {0, 0, 0};
+        for (int d = 0; d < D; ++d) { q[d] = yq[d]; cq[d] = knn_cell_of(g, d, q[d]); }
+        uint64_t mine = NONE, kth = NONE;
+        auto feed_range = [&](int c_lo, int c_hi, int cy, int cz) {   // cells c_lo .. c_hi of row (cy, cz): one range of perm
+            const int64_t row = ((int64_t)cz * g.g[1] + cy) * g.g[0];
+            const int p0 = rowptr[row + c_lo], p1 = rowptr[row + c_hi + 1];
+            for (int base = p0; base < p1; base += 64) {
+                const int p = base + lane;
+                uint64_t key = NONE;
+                if (p < p1) {
+                    const int i = perm[p];
+                    const float d = dist2<float>(x + (int64_t)i * D, yq, D);
+                    if (d == d) key = ((uint64_t)knn_order(d) << 32) | (uint32_t)i;
+                }
+                uint64_t todo = __ballot(key < kth);
+                while (todo) {
+                    const int src = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint64_t c = shfl_u64(key, src);
+                    if (!(c < kth)) continue;
+                    const int pos = __popcll(__ballot(mine < c));
+                    const uint64_t up = shfl_up_u64(mine);
+                    mine = lane < pos ? mine : (lane == pos ? c : up);
+                    kth = shfl_u64(mine, k - 1);
+                }
+            }
+        };
+        const int smax = (g.g[0] > g.g[1] ? (g.g[0] > g.g[2] ? g.g[0] : g.g[2]) : (g.g[1] > g.g[2] ? g.g[1] : g.g[2]));
+        for (int s = 0; s < smax; ++s) {
+            const int z0 = cq[2] - s < 0 ? 0 : cq[2] - s, z1 = cq[2] + s > g.g[2] - 1 ? g.g[2] - 1 : cq[2] + s;
+            const int y0 = cq[1] - s < 0 ? 0 : cq[1] - s, y1 = cq[1] + s > g.g[1] - 1 ? g.g[1] - 1 : cq[1] + s;
+            const int x0 = cq[0] - s < 0 ? 0 : cq[0] - s, x1 = cq[0] + s > g.g[0] - 1 ? g.g[0] - 1 : cq[0] + s;
+            for (int cz = z0; cz <= z1; ++cz)
+                for (int cy = y0; cy <= y1; ++cy) {
+                    const int az = cz > cq[2] ? cz - cq[2] : cq[2] - cz, ay = cy > cq[1] ? cy - cq[1] : cq[1] - cy;
+                    if ((az > ay ? az : ay) == s) {
+                        feed_range(x0, x1, cy, cz);            // a row of the shell's outer faces: all of it is new
+                    } else {                                    // an inner row: only its two end cells are new
+                        if (cq[0] - s >= 0) feed_range(cq[0] - s, cq[0] - s, cy, cz);
+                        if (cq[0] + s <= g.g[0] - 1) feed_range(cq[0] + s, cq[0] + s, cy, cz);
+                    }
+                }
+            // done? the block covers the grid, or nothing outside it can beat the k-th key
+            bool whole = true;
+            float bound = __builtin_huge_valf();
+            for (int d = 0; d < 3; ++d) {
+                if (g.g[d] == 1) continue;
+                if (cq[d] - s > 0) {
+                    whole = false;
+                    const float f = q[d] - (g.lo[d] + (float)(cq[d] - s) * g.h[d]) - 1e-3f * g.h[d];
+                    bound = f < bound ? f : bound;
+                }
+                if (cq[d] + s < g.g[d] - 1) {
+                    whole = false;
+                    const float f = (g.lo[d] + (float)(cq[d] + s + 1) * g.h[d]) - q[d] - 1e-3f * g.h[d];
+                    bound = f < bound ? f : bound;
+                }
+            }
+            if (whole) break;
+            if (kth != NONE && bound > 0.f && knn_unorder((uint32_t)(kth >> 32)) < bound * bound) break;
+        }
+        if (lane < k) col[qy * k + lane] = mine == NONE ? (int64_t)-1 : (int64_t)(uint32_t)mine;
+    }
+}
+
 // ---- radius: wave per query, candidates in index order, the first `max_nb` with squared distance < r^2 ----
 template <typename T>
 __global__ __launch_bounds__(256) void radius_kernel(const T* __restrict__ x, const T* __restrict__ y, const int64_t* __restrict__ ptr_x,
@@ -382,6 +530,35 @@ extern "C" int gnnops_knn(const void* x, const void* y, const int64_t* ptr_x, co
                                                   ptr_y, (int)batches, Ny, D, k, col), "knn")
     }
     return gnnops_check_launch("knn");
+}
+
+// Step 1 of the grid form: bounding box of x (6 words at `box`, device) and the cell id of every point (int64, the plan
+// builder's index type). G cells per axis, G^D < 2^31. Then gnnops_plan_build(cell, Nx, G^D, rowptr, perm) and step 2.
+extern "C" int gnnops_knn_grid_cells(const void* x, int64_t Nx, int D, int G, void* box, int64_t* cell, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(Nx >= 0 && D >= 1 && D <= 3 && G >= 1, GNNOPS_EINVAL, "knn_grid_cells: bad shape");
+    GNNOPS_REQUIRE(box && (Nx == 0 || (x && cell)), GNNOPS_EINVAL, "knn_grid_cells: null pointer");
+    hipStream_t stream = (hipStream_t)s;
+    // images: min side starts at all ones, max side at zero
+    if (gnnops_memset_async(box, 0xff, 12, stream) != hipSuccess || gnnops_memset_async((char*)box + 12, 0, 12, stream) != hipSuccess)
+        return gnnops_check_launch("knn_grid_cells init");
+    if (Nx == 0) return GNNOPS_OK;
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(gnnops_grid_cap(gnnops_cdiv(Nx, 1024), 1024)), dim3(256), 0, stream, (const float*)x, Nx, D,
+                       (unsigned*)box);
+    hipLaunchKernelGGL(knn_cells_kernel, dim3(gnnops_grid_cap(gnnops_cdiv(Nx, 256))), dim3(256), 0, stream, (const float*)x, Nx, D, G,
+                       (const unsigned*)box, cell);
+    return gnnops_check_launch("knn_grid_cells");
+}
+
+// Step 2: for every y its k nearest x (fp32, Euclidean, one cloud, k <= 64), nearest first, -1 where there are fewer: [Ny, k].
+extern "C" int gnnops_knn_grid_query(const void* x, const void* y, int64_t Ny, int D, int k, int G, const void* box, const int32_t* rowptr,
+                                     const int32_t* perm, int64_t* col, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(Ny >= 0 && D >= 1 && D <= 3 && G >= 1 && k >= 1 && k <= 64, GNNOPS_EINVAL, "knn_grid_query: bad shape");
+    if (Ny == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(x && y && box && rowptr && perm && col, GNNOPS_EINVAL, "knn_grid_query: null pointer");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(Ny, 4), 256 * 32);
+    hipLaunchKernelGGL(knn_grid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)y, Ny, D, k, G,
+                       (const unsigned*)box, rowptr, perm, col);
+    return gnnops_check_launch("knn_grid_query");
 }
 
 extern "C" int gnnops_radius(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,

@@ -207,6 +207,35 @@ def _pairs(col, k):
     return torch.stack([row[mask], col[mask]], dim=0)
 
 
+_KNN_GRID_MIN_POINTS = 8192     # one cloud of at least this many points is searched through a uniform grid (csrc/cluster.hip)
+_KNN_GRID_PER_CELL = 8          # points per cell aimed at
+
+
+def _knn_grid(x, y, k):
+    """One cloud, Euclidean, D <= 3, fp32, k <= 64: bin x into G^D cells of its bounding box, order the points by cell with
+    the plan builder (cell = destination: rowptr = first point of each cell, perm = points in cell order) and let every
+    query walk the cells around its own. Everything stays on the stream; the pairs are the exhaustive kernel's."""
+    L = _lib.load()
+    nx, D = x.shape
+    G = int(round((nx / _KNN_GRID_PER_CELL) ** (1.0 / D)))
+    G = max(1, min(G, 1023 if D == 3 else 2048 if D == 2 else 4096))
+    cells = G ** D
+    dev = x.device
+    box = torch.empty(6, dtype=torch.int32, device=dev)
+    cell = torch.empty(nx, dtype=torch.int64, device=dev)
+    rowptr = torch.empty(cells + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(nx, dtype=torch.int32, device=dev)
+    ws_bytes = L.gnnops_plan_workspace_bytes(nx, cells)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    col = torch.empty((y.size(0), k), dtype=torch.int64, device=dev)
+    with _on(dev):
+        check(L.gnnops_knn_grid_cells(x.data_ptr(), nx, D, G, box.data_ptr(), cell.data_ptr(), _stream()), "knn_grid_cells")
+        check(L.gnnops_plan_build(cell.data_ptr(), nx, cells, rowptr.data_ptr(), perm.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "plan_build")
+        check(L.gnnops_knn_grid_query(x.data_ptr(), y.data_ptr(), y.size(0), D, k, G, box.data_ptr(), rowptr.data_ptr(), perm.data_ptr(),
+                                      col.data_ptr(), _stream()), "knn_grid_query")
+    return col
+
+
 def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
     """torch_cluster.knn(x, y, k, batch_x, batch_y, cosine): for every y its k nearest x of the same batch, nearest first:
     int64 [2, M] = (index into y, index into x)."""
@@ -214,6 +243,9 @@ def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
     if x.size(1) != y.size(1) or x.dtype != y.dtype:
         raise RuntimeError("knn: x and y need the same width and dtype")
     dt = _dtype_code(x, "knn")
+    if (batch_x is None and batch_y is None and not cosine and x.dtype == torch.float32 and x.size(1) <= 3 and 1 <= int(k) <= 64
+            and x.size(0) >= _KNN_GRID_MIN_POINTS and x.size(0) < 2 ** 31):
+        return _pairs(_knn_grid(x, y, int(k)), k)
     ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
     col = torch.empty((y.size(0), k), dtype=torch.int64, device=x.device)
     with _on(x.device):

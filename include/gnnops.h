@@ -483,6 +483,12 @@ int gnnops_grid_cluster(const void* pos, int64_t N, int D, const double* d_size,
                         int64_t* cluster, int dtype, gnnops_stream_t stream);
 int gnnops_knn(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,
                int k, int cosine, int64_t* col, int dtype, gnnops_stream_t stream);
+/* torch_cluster.knn through a uniform grid — one cloud, Euclidean, D <= 3, fp32, k <= 64; the pairs of the exhaustive kernel.
+ * Step 1: bounding box (24 bytes at `box`) and cell ids of x on a G^D grid; then gnnops_plan_build(cell, Nx, G^D, rowptr, perm);
+ * step 2: the queries walk the cells around their own in shells until the k-th distance is inside the block searched. */
+int gnnops_knn_grid_cells(const void* x, int64_t Nx, int D, int G, void* box, int64_t* cell, gnnops_stream_t stream);
+int gnnops_knn_grid_query(const void* x, const void* y, int64_t Ny, int D, int k, int G, const void* box, const int32_t* rowptr,
+                          const int32_t* perm, int64_t* col, gnnops_stream_t stream);
 int gnnops_radius(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,
                   double r, int max_num_neighbors, int64_t* col, int dtype, gnnops_stream_t stream);
 int gnnops_fps(const void* x, const int64_t* ptr, const int64_t* out_ptr, const int64_t* start, int64_t batches, int D,

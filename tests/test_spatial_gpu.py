@@ -179,6 +179,48 @@ def test_knn_one_pass_equals_k_rounds(k, cosine, monkeypatch):
     assert int(per_query[by == 3].max()) == min(k, 9)
 
 
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("k", [1, 9, 64])
+def test_knn_through_the_grid_equals_the_exhaustive_kernel(D, k, monkeypatch):
+    """One cloud of >= 8192 fp32 points in <= 3 dimensions is searched through a uniform grid (gnnops_knn_grid_cells -> plan ->
+    gnnops_knn_grid_query): the same pairs in the same order as the exhaustive kernel, on clouds made to hurt — a dense clump
+    beside empty space (many empty cells, long walks), a coarse lattice (exact ties across cell faces), duplicated points,
+    a flat axis, NaN and infinite coordinates among x, queries outside the box / NaN, fewer finite candidates than k never
+    (that needs a tiny cloud: covered by the exhaustive tests)."""
+    from torch_cluster import knn
+    from gnnops import spatial
+
+    g = torch.Generator().manual_seed(50 + 10 * D + k)
+    n = 20000
+    x = torch.rand(n, D, generator=g)
+    x[:6000] = x[:6000] * 0.02 + 0.4                       # clump
+    x[6000:9000] = (torch.randint(0, 12, (3000, D), generator=g).float() / 12)   # lattice
+    x[9000:9100] = x[8900:9000]                             # duplicates
+    if D == 3:
+        x[9100:12000, 2] = 0.5                              # a slab
+    x[123] = float("nan")
+    x[456, 0] = float("inf")
+    y = torch.rand(900, D, generator=g) * 1.6 - 0.3         # a third of the queries outside the box
+    y[:200] = x[6000:6200]                                  # queries ON lattice points
+    y[5] = float("nan")
+    calls = []
+    real = spatial._knn_grid
+    monkeypatch.setattr(spatial, "_knn_grid", lambda *a: (calls.append(1), real(*a))[1])
+    got = knn(x.cuda(), y.cuda(), k)
+    assert calls == [1], "the grid form did not take the call"
+    monkeypatch.setattr(spatial, "_KNN_GRID_MIN_POINTS", 1 << 40)
+    ref = knn(x.cuda(), y.cuda(), k)
+    assert calls == [1]
+    assert torch.equal(got, ref)
+    assert not bool((got[1] == 123).any())
+    # a flat cloud (every point the same): one cell, every query walks it
+    flat = torch.full((9000, D), 0.25)
+    assert torch.equal(knn(flat.cuda(), y[:50].cuda(), k), knn(flat[:9000].cuda(), y[:50].cuda(), k))
+    monkeypatch.setattr(spatial, "_KNN_GRID_MIN_POINTS", 8192)
+    got_flat = knn(flat.cuda(), y[10:50].cuda(), k)
+    assert got_flat[1].view(40, k).cpu().tolist() == [list(range(k))] * 40
+
+
 @pytest.mark.parametrize("batches", [1, 4])
 def test_radius_and_radius_graph(ora, batches):
     from torch_cluster import radius, radius_graph
