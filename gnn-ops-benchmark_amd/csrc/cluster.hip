@@ -230,9 +230,13 @@ __global__ void knn_cells_kernel(const float* __restrict__ x, int64_t n, int D, 
     }
 }
 
+// RADIUS: the same walk for torch_cluster.radius — the key is the index alone among the points with |x - y|^2 < r2, so the list
+// ends up holding the k = max_num_neighbors SMALLEST indices inside the ball (what the exhaustive kernel's index-order scan
+// returns), and the walk ends when no point outside the block can be inside the ball.
+template <bool RADIUS>
 __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t Ny, int D, int k, int G,
                                                        const unsigned* __restrict__ box, const int32_t* __restrict__ rowptr,
-                                                       const int32_t* __restrict__ perm, int64_t* __restrict__ col) {
+                                                       const int32_t* __restrict__ perm, int64_t* __restrict__ col, float r2) {
     const KnnGrid g = knn_grid_of(box, D, G);
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -252,7 +256,8 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
                 if (p < p1) {
                     const int i = perm[p];
                     const float d = dist2<float>(x + (int64_t)i * D, yq, D);
-                    if (d == d) key = ((uint64_t)knn_order(d) << 32) | (uint32_t)i;
+                    if constexpr (RADIUS) { if (d < r2) key = (uint64_t)(uint32_t)i; }
+                    else if (d == d) key = ((uint64_t)knn_order(d) << 32) | (uint32_t)i;
                 }
                 uint64_t todo = __ballot(key < kth);
                 while (todo) {
@@ -299,7 +304,8 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
                 }
             }
             if (whole) break;
-            if (kth != NONE && bound > 0.f && knn_unorder((uint32_t)(kth >> 32)) < bound * bound) break;
+            if constexpr (RADIUS) { if (bound > 0.f && bound * bound >= r2) break; }
+            else if (kth != NONE && bound > 0.f && knn_unorder((uint32_t)(kth >> 32)) < bound * bound) break;
         }
         if (lane < k) col[qy * k + lane] = mine == NONE ? (int64_t)-1 : (int64_t)(uint32_t)mine;
     }
@@ -556,9 +562,22 @@ extern "C" int gnnops_knn_grid_query(const void* x, const void* y, int64_t Ny, i
     if (Ny == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(x && y && box && rowptr && perm && col, GNNOPS_EINVAL, "knn_grid_query: null pointer");
     const int grid = gnnops_grid_cap(gnnops_cdiv(Ny, 4), 256 * 32);
-    hipLaunchKernelGGL(knn_grid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)y, Ny, D, k, G,
-                       (const unsigned*)box, rowptr, perm, col);
+    hipLaunchKernelGGL(knn_grid_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)y, Ny, D, k, G,
+                       (const unsigned*)box, rowptr, perm, col, 0.f);
     return gnnops_check_launch("knn_grid_query");
+}
+
+// torch_cluster.radius through the same grid: col [Ny, max_num_neighbors] = the smallest indices with |x - y|^2 < r^2, ascending.
+extern "C" int gnnops_radius_grid_query(const void* x, const void* y, int64_t Ny, int D, double r, int max_num_neighbors, int G, const void* box,
+                                        const int32_t* rowptr, const int32_t* perm, int64_t* col, gnnops_stream_t s) {
+    GNNOPS_REQUIRE(Ny >= 0 && D >= 1 && D <= 3 && G >= 1 && max_num_neighbors >= 1 && max_num_neighbors <= 64, GNNOPS_EINVAL,
+                   "radius_grid_query: bad shape");
+    if (Ny == 0) return GNNOPS_OK;
+    GNNOPS_REQUIRE(x && y && box && rowptr && perm && col, GNNOPS_EINVAL, "radius_grid_query: null pointer");
+    const int grid = gnnops_grid_cap(gnnops_cdiv(Ny, 4), 256 * 32);
+    hipLaunchKernelGGL(knn_grid_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)y, Ny, D, max_num_neighbors, G,
+                       (const unsigned*)box, rowptr, perm, col, (float)(r * r));
+    return gnnops_check_launch("radius_grid_query");
 }
 
 extern "C" int gnnops_radius(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,

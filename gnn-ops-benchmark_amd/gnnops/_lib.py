@@ -89,6 +89,7 @@ SIGNATURES = {
     "gnnops_knn": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _ci, _ci, _ci, _vp, _ci, _vp]),
     "gnnops_knn_grid_cells": (_ci, [_vp, _i64, _ci, _ci, _vp, _vp, _vp]),
     "gnnops_knn_grid_query": (_ci, [_vp, _vp, _i64, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "gnnops_radius_grid_query": (_ci, [_vp, _vp, _i64, _ci, ctypes.c_double, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
     "gnnops_radius": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _ci, ctypes.c_double, _ci, _vp, _ci, _vp]),
     "gnnops_fps": (_ci, [_vp, _vp, _vp, _vp, _i64, _ci, _vp, _vp, _ci, _vp]),
     "gnnops_random_walk": (_ci, [_vp, _vp, _vp, _i64, _ci, ctypes.c_uint64, _vp, _vp]),

@@ -211,10 +211,11 @@ _KNN_GRID_MIN_POINTS = 8192     # one cloud of at least this many points is sear
 _KNN_GRID_PER_CELL = 8          # points per cell aimed at
 
 
-def _knn_grid(x, y, k):
+def _knn_grid(x, y, k, radius=None):
     """One cloud, Euclidean, D <= 3, fp32, k <= 64: bin x into G^D cells of its bounding box, order the points by cell with
     the plan builder (cell = destination: rowptr = first point of each cell, perm = points in cell order) and let every
-    query walk the cells around its own. Everything stays on the stream; the pairs are the exhaustive kernel's."""
+    query walk the cells around its own. Everything stays on the stream; the pairs are the exhaustive kernel's.
+    radius = r: torch_cluster.radius instead — the k smallest indices inside the ball."""
     L = _lib.load()
     nx, D = x.shape
     G = int(round((nx / _KNN_GRID_PER_CELL) ** (1.0 / D)))
@@ -231,8 +232,12 @@ def _knn_grid(x, y, k):
     with _on(dev):
         check(L.gnnops_knn_grid_cells(x.data_ptr(), nx, D, G, box.data_ptr(), cell.data_ptr(), _stream()), "knn_grid_cells")
         check(L.gnnops_plan_build(cell.data_ptr(), nx, cells, rowptr.data_ptr(), perm.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "plan_build")
-        check(L.gnnops_knn_grid_query(x.data_ptr(), y.data_ptr(), y.size(0), D, k, G, box.data_ptr(), rowptr.data_ptr(), perm.data_ptr(),
-                                      col.data_ptr(), _stream()), "knn_grid_query")
+        if radius is None:
+            check(L.gnnops_knn_grid_query(x.data_ptr(), y.data_ptr(), y.size(0), D, k, G, box.data_ptr(), rowptr.data_ptr(), perm.data_ptr(),
+                                          col.data_ptr(), _stream()), "knn_grid_query")
+        else:
+            check(L.gnnops_radius_grid_query(x.data_ptr(), y.data_ptr(), y.size(0), D, float(radius), k, G, box.data_ptr(), rowptr.data_ptr(),
+                                             perm.data_ptr(), col.data_ptr(), _stream()), "radius_grid_query")
     return col
 
 
@@ -272,6 +277,9 @@ def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32, num_worker
     if x.size(1) != y.size(1) or x.dtype != y.dtype:
         raise RuntimeError("radius: x and y need the same width and dtype")
     dt = _dtype_code(x, "radius")
+    if (batch_x is None and batch_y is None and x.dtype == torch.float32 and x.size(1) <= 3 and 1 <= int(max_num_neighbors) <= 64
+            and x.size(0) >= _KNN_GRID_MIN_POINTS and x.size(0) < 2 ** 31 and float(r) >= 0):
+        return _pairs(_knn_grid(x, y, int(max_num_neighbors), radius=r), max_num_neighbors)
     ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
     col = torch.empty((y.size(0), max_num_neighbors), dtype=torch.int64, device=x.device)
     with _on(x.device):

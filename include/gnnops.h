@@ -489,6 +489,9 @@ int gnnops_knn(const void* x, const void* y, const int64_t* ptr_x, const int64_t
 int gnnops_knn_grid_cells(const void* x, int64_t Nx, int D, int G, void* box, int64_t* cell, gnnops_stream_t stream);
 int gnnops_knn_grid_query(const void* x, const void* y, int64_t Ny, int D, int k, int G, const void* box, const int32_t* rowptr,
                           const int32_t* perm, int64_t* col, gnnops_stream_t stream);
+/* torch_cluster.radius over the same cells / plan: the max_num_neighbors (<= 64) smallest indices inside the ball, ascending. */
+int gnnops_radius_grid_query(const void* x, const void* y, int64_t Ny, int D, double r, int max_num_neighbors, int G, const void* box,
+                             const int32_t* rowptr, const int32_t* perm, int64_t* col, gnnops_stream_t stream);
 int gnnops_radius(const void* x, const void* y, const int64_t* ptr_x, const int64_t* ptr_y, int64_t batches, int64_t Ny, int D,
                   double r, int max_num_neighbors, int64_t* col, int dtype, gnnops_stream_t stream);
 int gnnops_fps(const void* x, const int64_t* ptr, const int64_t* out_ptr, const int64_t* start, int64_t batches, int D,

@@ -221,6 +221,35 @@ def test_knn_through_the_grid_equals_the_exhaustive_kernel(D, k, monkeypatch):
     assert got_flat[1].view(40, k).cpu().tolist() == [list(range(k))] * 40
 
 
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("r,cap", [(0.03, 32), (0.11, 64), (0.5, 7), (0.0, 4)])
+def test_radius_through_the_grid_equals_the_exhaustive_kernel(D, r, cap, monkeypatch):
+    """torch_cluster.radius on one cloud of >= 8192 fp32 points walks the same grid: the `cap` smallest indices inside the ball,
+    ascending — the exhaustive kernel's answer — for balls smaller than a cell, spanning many cells, covering half the cloud,
+    and empty (r = 0: the comparison is strict)."""
+    from torch_cluster import radius
+    from gnnops import spatial
+
+    g = torch.Generator().manual_seed(70 + D)
+    n = 15000
+    x = torch.rand(n, D, generator=g)
+    x[:4000] = x[:4000] * 0.05 + 0.2
+    x[4000:6000] = torch.randint(0, 10, (2000, D), generator=g).float() / 10
+    x[77] = float("nan")
+    y = torch.rand(500, D, generator=g) * 1.4 - 0.2
+    y[:100] = x[4000:4100]
+    calls = []
+    real = spatial._knn_grid
+    monkeypatch.setattr(spatial, "_knn_grid", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    got = radius(x.cuda(), y.cuda(), r, max_num_neighbors=cap)
+    assert calls == [1]
+    monkeypatch.setattr(spatial, "_KNN_GRID_MIN_POINTS", 1 << 40)
+    ref = radius(x.cuda(), y.cuda(), r, max_num_neighbors=cap)
+    assert calls == [1] and torch.equal(got, ref)
+    if r == 0.0:
+        assert got.numel() == 0
+
+
 @pytest.mark.parametrize("batches", [1, 4])
 def test_radius_and_radius_graph(ora, batches):
     from torch_cluster import radius, radius_graph
