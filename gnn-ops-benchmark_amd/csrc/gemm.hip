@@ -1087,6 +1087,9 @@ inline int cu_count() {
 inline int sk_split_of(int64_t T, int G) {
     const char* sw = getenv("GNNOPS_GEMM_SK");  // A/B (tools/time_gemm_sk.py): 0 = off, 3 = persistent loop for whole rounds too
     if (sw && sw[0] == '0') return 1;
+    // T < G (every tile a "last round" tile, cut so that most CUs get a piece) was tried and lost: 49 tiles of L = 1581 as
+    // 196 pieces 54 vs 41 us, 64 tiles of L = 2000 58 vs 37, 100 tiles as 200 pieces 75 vs 75 — three to seven 192-KiB partial
+    // tiles per workgroup cost more than the short K loops save (profiles/round3_f_gemm_streamk.txt)
     if ((G & 7) != 0 || T < G) return 1;
     const int64_t r = T % G;
     if (r == 0) return (sw && sw[0] == '3') ? 8 : 1;

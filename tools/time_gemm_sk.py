@@ -29,7 +29,7 @@ for dt in dts:
         ref = (c[rows].double() + a[rows].double() @ b.double())
         base = None
         line = f"{str(dt)[6:]:9s} L={L:5d} tiles={(-(-L // 256)) ** 2:5d}"
-        for sk in ("0", "", "0", "", "0", ""):
+        for sk in (os.environ.get("SK_MODES", "0,,0,,0,").split(",")):
             if sk: os.environ["GNNOPS_GEMM_SK"] = sk
             else: os.environ.pop("GNNOPS_GEMM_SK", None)
             us, out = timed(a, b, c)
