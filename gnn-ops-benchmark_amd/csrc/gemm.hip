@@ -1963,8 +1963,6 @@ extern "C" int gnnops_addmm_ld(const void* input, int64_t ldadd, const void* mat
                            g.Kmain, bt_elems);
         w += g.at_bytes + g.bt_bytes;
     }
-    GNNOPS_REQUIRE(g.path == 0 || !(g.copy_a || g.copy_b) || K == 0 || ((uintptr_t)mat1 % 16 == 0 && (uintptr_t)mat2 % 16 == 0),
-                   GNNOPS_EUNSUPPORTED, "addmm: operand base pointers must be 16-byte aligned");
     if (g.path == 2 && g.sk_split > 1)
         return dtype == GNNOPS_BF16
                    ? launch_sk256<__hip_bfloat16, true>(input, mat1, mat2, out, M, N, g.Kp, lda, ldb, ldadd, at, bt, g.Kmain, w, g.sk_split, stream)

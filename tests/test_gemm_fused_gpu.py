@@ -202,6 +202,24 @@ def test_addmm_operands_read_in_place(gnnops, M, N, K, dname):
     assert bool((err <= bound).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(6000, 5200, 5100), (1536, 1536, 520), (4352, 4352, 1024)])
+def test_addmm_operands_at_odd_offsets(gnnops, M, N, K):
+    """Operands that start 2 bytes into their allocation (a slice of a flat buffer): the LDS-DMA kernels read them where they lie,
+    with A copied whole (first shape: > 30 M elements), with both in place, and through the split-K kernel. Against the same
+    product from 256-B aligned copies of the operands: bit-identical."""
+    g = torch.Generator(device="cuda").manual_seed(15)
+    def odd(rows, cols):
+        buf = torch.empty(rows * cols + 9, dtype=torch.float16, device="cuda")
+        v = buf[1:1 + rows * cols].view(rows, cols)
+        v.copy_((torch.rand(rows, cols, generator=g, device="cuda") - 0.5).half())
+        assert v.data_ptr() % 4 == 2
+        return v
+    A, B, C = odd(M, K), odd(K, N), odd(M, N)
+    got = gnnops.addmm(C, A, B)
+    ref = gnnops.addmm(C.clone(), A.clone(), B.clone())
+    assert torch.equal(got, ref)
+
+
 def test_addmm_big_tiles_identity(gnnops):
     n = 4096
     B = (torch.arange(n * n).view(n, n) % 251).to(torch.bfloat16)
