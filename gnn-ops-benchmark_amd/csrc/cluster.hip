@@ -292,14 +292,19 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
             float bound = __builtin_huge_valf();
             for (int d = 0; d < 3; ++d) {
                 if (g.g[d] == 1) continue;
+                // box-relative coordinates, as the cell arithmetic uses them: a cloud far from the origin (coordinates 1000.0 ..
+                // 1000.1) would lose the faces to the rounding of lo + c h. The margin covers a point the float division put
+                // one cell off (~1e-4 h at G = 1000) and the rounding of q - lo for a query far outside the box.
+                const float qr = q[d] - g.lo[d];
+                const float margin = 1e-3f * g.h[d] + 1e-6f * (qr < 0.f ? -qr : qr);
                 if (cq[d] - s > 0) {
                     whole = false;
-                    const float f = q[d] - (g.lo[d] + (float)(cq[d] - s) * g.h[d]) - 1e-3f * g.h[d];
+                    const float f = qr - (float)(cq[d] - s) * g.h[d] - margin;
                     bound = f < bound ? f : bound;
                 }
                 if (cq[d] + s < g.g[d] - 1) {
                     whole = false;
-                    const float f = (g.lo[d] + (float)(cq[d] + s + 1) * g.h[d]) - q[d] - 1e-3f * g.h[d];
+                    const float f = (float)(cq[d] + s + 1) * g.h[d] - qr - margin;
                     bound = f < bound ? f : bound;
                 }
             }

@@ -213,6 +213,12 @@ def test_knn_through_the_grid_equals_the_exhaustive_kernel(D, k, monkeypatch):
     assert calls == [1]
     assert torch.equal(got, ref)
     assert not bool((got[1] == 123).any())
+    # the same cloud far from the origin (coordinates around 3000: an ulp is a sizeable part of a cell) and queries far outside
+    xo, yo = x + 3000.0, torch.cat([y[:300] + 3000.0, y[300:600] * 500.0 - 7000.0])
+    monkeypatch.setattr(spatial, "_KNN_GRID_MIN_POINTS", 8192)
+    got_o = knn(xo.cuda(), yo.cuda(), k)
+    monkeypatch.setattr(spatial, "_KNN_GRID_MIN_POINTS", 1 << 40)
+    assert torch.equal(got_o, knn(xo.cuda(), yo.cuda(), k))
     # a flat cloud (every point the same): one cell, every query walks it
     flat = torch.full((9000, D), 0.25)
     assert torch.equal(knn(flat.cuda(), y[:50].cuda(), k), knn(flat[:9000].cuda(), y[:50].cuda(), k))
