@@ -209,6 +209,7 @@ def _pairs(col, k):
 
 _KNN_GRID_MIN_POINTS = 8192     # one cloud of at least this many points is searched through a uniform grid (csrc/cluster.hip)
 _KNN_GRID_PER_CELL = 8          # points per cell aimed at
+_KNN_GRID_MAX_BATCHES = 64      # with a batch vector: at most this many clouds are taken one by one so that the large ones get a grid
 
 
 def _knn_grid(x, y, k, radius=None):
@@ -241,6 +242,26 @@ def _knn_grid(x, y, k, radius=None):
     return col
 
 
+def _by_cloud(x, y, k, ptr_x, ptr_y, radius, exhaustive):
+    """A batch vector over a FEW clouds of which at least one is large (>= _KNN_GRID_MIN_POINTS points): the clouds are taken one by
+    one — the large ones walk a grid of their own, the others go through `exhaustive(x_slice, y_slice)` — and the neighbour
+    indices are shifted back by the cloud's first point. None when that does not apply (the caller makes its one exhaustive call)."""
+    B = ptr_x.numel() - 1
+    if B < 1 or B > _KNN_GRID_MAX_BATCHES or x.size(0) < _KNN_GRID_MIN_POINTS:
+        return None
+    px, py = ptr_x.tolist(), ptr_y.tolist()
+    if not any(px[b + 1] - px[b] >= _KNN_GRID_MIN_POINTS and py[b + 1] > py[b] for b in range(B)):
+        return None
+    col = torch.full((y.size(0), k), -1, dtype=torch.int64, device=x.device)
+    for b in range(B):
+        if py[b + 1] == py[b] or px[b + 1] == px[b]:
+            continue
+        xs, ys = x[px[b]:px[b + 1]], y[py[b]:py[b + 1]]
+        part = _knn_grid(xs, ys, k, radius=radius) if xs.size(0) >= _KNN_GRID_MIN_POINTS else exhaustive(xs, ys)
+        col[py[b]:py[b + 1]] = torch.where(part >= 0, part + px[b], part)
+    return col
+
+
 def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
     """torch_cluster.knn(x, y, k, batch_x, batch_y, cosine): for every y its k nearest x of the same batch, nearest first:
     int64 [2, M] = (index into y, index into x)."""
@@ -252,10 +273,21 @@ def knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
             and x.size(0) >= _KNN_GRID_MIN_POINTS and x.size(0) < 2 ** 31):
         return _pairs(_knn_grid(x, y, int(k)), k)
     ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
-    col = torch.empty((y.size(0), k), dtype=torch.int64, device=x.device)
-    with _on(x.device):
-        check(_lib.load().gnnops_knn(x.data_ptr(), y.data_ptr(), ptr_x.data_ptr(), ptr_y.data_ptr(), ptr_x.numel() - 1, y.size(0), x.size(1),
-                                     int(k), 1 if cosine else 0, col.data_ptr(), dt, _stream()), "knn")
+
+    def exhaustive(xs, ys, px=None, py=None):
+        px = _ptr_of(None, xs.size(0), xs.device) if px is None else px
+        py = _ptr_of(None, ys.size(0), xs.device) if py is None else py
+        out = torch.empty((ys.size(0), k), dtype=torch.int64, device=xs.device)
+        with _on(xs.device):
+            check(_lib.load().gnnops_knn(xs.data_ptr(), ys.data_ptr(), px.data_ptr(), py.data_ptr(), px.numel() - 1, ys.size(0), xs.size(1),
+                                         int(k), 1 if cosine else 0, out.data_ptr(), dt, _stream()), "knn")
+        return out
+
+    col = None
+    if not cosine and x.dtype == torch.float32 and x.size(1) <= 3 and 1 <= int(k) <= 64 and x.size(0) < 2 ** 31:
+        col = _by_cloud(x, y, int(k), ptr_x, ptr_y, None, exhaustive)
+    if col is None:
+        col = exhaustive(x, y, ptr_x, ptr_y)
     return _pairs(col, k)
 
 
@@ -281,10 +313,21 @@ def radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32, num_worker
             and x.size(0) >= _KNN_GRID_MIN_POINTS and x.size(0) < 2 ** 31 and float(r) >= 0):
         return _pairs(_knn_grid(x, y, int(max_num_neighbors), radius=r), max_num_neighbors)
     ptr_x, ptr_y = _pair_ptrs(x, y, batch_x, batch_y)
-    col = torch.empty((y.size(0), max_num_neighbors), dtype=torch.int64, device=x.device)
-    with _on(x.device):
-        check(_lib.load().gnnops_radius(x.data_ptr(), y.data_ptr(), ptr_x.data_ptr(), ptr_y.data_ptr(), ptr_x.numel() - 1, y.size(0), x.size(1),
-                                        float(r), int(max_num_neighbors), col.data_ptr(), dt, _stream()), "radius")
+
+    def exhaustive(xs, ys, px=None, py=None):
+        px = _ptr_of(None, xs.size(0), xs.device) if px is None else px
+        py = _ptr_of(None, ys.size(0), xs.device) if py is None else py
+        out = torch.empty((ys.size(0), max_num_neighbors), dtype=torch.int64, device=xs.device)
+        with _on(xs.device):
+            check(_lib.load().gnnops_radius(xs.data_ptr(), ys.data_ptr(), px.data_ptr(), py.data_ptr(), px.numel() - 1, ys.size(0), xs.size(1),
+                                            float(r), int(max_num_neighbors), out.data_ptr(), dt, _stream()), "radius")
+        return out
+
+    col = None
+    if x.dtype == torch.float32 and x.size(1) <= 3 and 1 <= int(max_num_neighbors) <= 64 and x.size(0) < 2 ** 31 and float(r) >= 0:
+        col = _by_cloud(x, y, int(max_num_neighbors), ptr_x, ptr_y, r, exhaustive)
+    if col is None:
+        col = exhaustive(x, y, ptr_x, ptr_y)
     return _pairs(col, max_num_neighbors)
 
 

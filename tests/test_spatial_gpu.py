@@ -227,6 +227,31 @@ def test_knn_through_the_grid_equals_the_exhaustive_kernel(D, k, monkeypatch):
     assert got_flat[1].view(40, k).cpu().tolist() == [list(range(k))] * 40
 
 
+def test_knn_and_radius_grid_per_cloud_under_a_batch_vector(monkeypatch):
+    """A batch vector over a few clouds of which some are large: the large ones walk a grid of their own, the small ones (and an
+    empty one) the exhaustive kernel, cloud by cloud; the pairs are those of the single exhaustive call over all of them."""
+    from torch_cluster import knn, radius
+    from gnnops import spatial
+
+    g = torch.Generator().manual_seed(91)
+    sizes_x = [9000, 300, 0, 12000, 50]
+    sizes_y = [400, 77, 5, 300, 0]
+    x = torch.cat([torch.rand(n, 3, generator=g) * (1 + b) for b, n in enumerate(sizes_x)])
+    y = torch.cat([torch.rand(n, 3, generator=g) * (1 + b) for b, n in enumerate(sizes_y)])
+    bx = torch.cat([torch.full((n,), b) for b, n in enumerate(sizes_x)])
+    by = torch.cat([torch.full((n,), b) for b, n in enumerate(sizes_y)])
+    calls = []
+    real = spatial._knn_grid
+    monkeypatch.setattr(spatial, "_knn_grid", lambda *a, **kw: (calls.append(a[0].size(0)), real(*a, **kw))[1])
+    got_k = knn(x.cuda(), y.cuda(), 12, bx.cuda(), by.cuda())
+    got_r = radius(x.cuda(), y.cuda(), 0.15, bx.cuda(), by.cuda(), max_num_neighbors=20)
+    assert calls == [9000, 12000, 9000, 12000]
+    monkeypatch.setattr(spatial, "_KNN_GRID_MIN_POINTS", 1 << 40)
+    assert torch.equal(got_k, knn(x.cuda(), y.cuda(), 12, bx.cuda(), by.cuda()))
+    assert torch.equal(got_r, radius(x.cuda(), y.cuda(), 0.15, bx.cuda(), by.cuda(), max_num_neighbors=20))
+    assert len(calls) == 4
+
+
 @pytest.mark.parametrize("D", [1, 2, 3])
 @pytest.mark.parametrize("r,cap", [(0.03, 32), (0.11, 64), (0.5, 7), (0.0, 4)])
 def test_radius_through_the_grid_equals_the_exhaustive_kernel(D, r, cap, monkeypatch):
