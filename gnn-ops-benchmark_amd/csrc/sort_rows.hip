@@ -28,9 +28,11 @@ constexpr int RADIX = 256;
 // THREADS x ROUNDS keys per row at most; LDS: keys u32[CAP] + pos u16[CAP] + per-wave histograms.
 // A "row" here is one SEGMENT of a matrix row: segs == 1 is the whole row of E_total keys; segs == 2 sorts the halves
 // [0, h0) and [h0, E_total) separately (indices stay positions in the whole row) for merge_halves_kernel below.
-template <int THREADS, int ROUNDS>
+// I: the index type written — int64 (what torch.sort returns) or int32 (positions fit: rows are at most 40000 long) for the halves
+// the merge reads back and for callers that widen the indices in a later pass (the dim-0 route's transposes, sparse.py).
+template <int THREADS, int ROUNDS, typename I>
 __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restrict__ in, float* __restrict__ values,
-                                                            int64_t* __restrict__ indices, int64_t rows, int E_total,
+                                                            I* __restrict__ indices, int64_t rows, int E_total,
                                                             int descending, int segs, int h0) {
     constexpr int WAVES = THREADS / 64;
     constexpr int CAP = THREADS * ROUNDS;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restr
             }
         }
         float* vdst = values + row * E_total + off;
-        int64_t* idst = indices + row * E_total + off;
+        I* idst = indices + row * E_total + off;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int i = wave_base + r * 64 + lane;
@@ -155,26 +157,26 @@ __global__ __launch_bounds__(THREADS) void sort_rows_kernel(const float* __restr
                 // a zero or a NaN: the key does not fix the bits (-0.0 keyed as +0.0, one key for all NaNs) — re-read the
                 // element (the row was just streamed: an L2 hit), so values == input.gather(indices) bit for bit
                 vdst[i] = (k == 0x80000000u || k == 0xffffffffu) ? src[e] : key_f32(k);
-                idst[i] = (int64_t)e + off;
+                idst[i] = (I)(e + (uint32_t)off);
             }
         }
     }
 }
 
-template <int THREADS, int ROUNDS>
-int launch(const float* in, float* values, int64_t* indices, int64_t rows, int E, int descending, hipStream_t stream,
+template <int THREADS, int ROUNDS, typename I>
+int launch(const float* in, float* values, I* indices, int64_t rows, int E, int descending, hipStream_t stream,
            int segs = 1, int h0 = 0) {
     constexpr int CAP = THREADS * ROUNDS;
     constexpr size_t LDS = (size_t)CAP * 6 + (size_t)(THREADS / 64) * RADIX * 4 + 64 * 4;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_rows_kernel<THREADS, ROUNDS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_rows_kernel<THREADS, ROUNDS, I>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess)
             return gnnops_check_launch("sort_rows attribute");
         configured = true;
     }
     const int grid = gnnops_grid_cap(rows * segs, 256 * 8);
-    hipLaunchKernelGGL((sort_rows_kernel<THREADS, ROUNDS>), dim3(grid), dim3(THREADS), LDS, stream, in, values, indices,
+    hipLaunchKernelGGL((sort_rows_kernel<THREADS, ROUNDS, I>), dim3(grid), dim3(THREADS), LDS, stream, in, values, indices,
                        rows * segs, E, descending, segs, segs == 1 ? E : h0);
     return gnnops_check_launch("sort_rows");
 }
@@ -186,16 +188,17 @@ int launch(const float* in, float* values, int64_t* indices, int64_t rows, int E
 // in all, against six-plus radix passes over 64-bit (segment, key) pairs.
 constexpr int MERGE_THREADS = 1024;
 
+template <typename I>
 __global__ __launch_bounds__(MERGE_THREADS) void merge_halves_kernel(const float* __restrict__ tmp_values,
-                                                                     const int64_t* __restrict__ tmp_indices,
-                                                                     float* __restrict__ values, int64_t* __restrict__ indices,
+                                                                     const int32_t* __restrict__ tmp_indices,
+                                                                     float* __restrict__ values, I* __restrict__ indices,
                                                                      int64_t rows, int E, int h0, int descending) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mg_raw[];
     uint32_t* k = reinterpret_cast<uint32_t*>(mg_raw);  // [E] order images (complemented when descending: ascending here)
     const int h1 = E - h0;
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const float* tv = tmp_values + row * E;
-        const int64_t* ti = tmp_indices + row * E;
+        const int32_t* ti = tmp_indices + row * E;
         __syncthreads();
         for (int i = threadIdx.x; i < E; i += MERGE_THREADS) {
             const uint32_t key = f32_key(tv[i]);
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_halves_kernel(const float
         }
         __syncthreads();
         for (int i0 = threadIdx.x; i0 < E; i0 += MERGE_THREADS * 4) {
-            int64_t src_idx[4];
+            int32_t src_idx[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {  // unconditional, clamped: the four index loads are in flight together
                 const int i = i0 + u * MERGE_THREADS;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_halves_kernel(const float
                     pos = (i - h0) + lo;
                 }
                 values[row * E + pos] = tv[i];
-                indices[row * E + pos] = src_idx[u];
+                indices[row * E + pos] = (I)src_idx[u];
             }
         }
     }
@@ -236,31 +239,38 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_halves_kernel(const float
 // Largest row length the on-chip form takes.
 extern "C" int64_t gnnops_sort_rows_max_len(void) { return 1024 * 22; }
 
-// input / values [rows, E] fp32, indices [rows, E] int64; sorted along E. E <= gnnops_sort_rows_max_len().
-extern "C" int gnnops_sort_rows_f32(const float* input, float* values, int64_t* indices, int64_t rows, int64_t E,
-                                    int descending, gnnops_stream_t s) {
-    hipStream_t stream = (hipStream_t)s;
+template <typename I>
+static int sort_rows_any(const float* input, float* values, I* indices, int64_t rows, int64_t E, int descending, hipStream_t stream) {
     GNNOPS_REQUIRE(rows >= 0 && E >= 0, GNNOPS_EINVAL, "sort_rows: negative size");
     GNNOPS_REQUIRE(E <= gnnops_sort_rows_max_len(), GNNOPS_EUNSUPPORTED, "sort_rows: row length %lld exceeds %lld",
                    (long long)E, (long long)gnnops_sort_rows_max_len());
     if (rows * E == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(input && values && indices, GNNOPS_EINVAL, "sort_rows: null pointer");
     const int e = (int)E;
-    if (E <= 256 * 4) return launch<256, 4>(input, values, indices, rows, e, descending, stream);
-    if (E <= 1024 * 4) return launch<1024, 4>(input, values, indices, rows, e, descending, stream);
-    if (E <= 1024 * 8) return launch<1024, 8>(input, values, indices, rows, e, descending, stream);
-    if (E <= 1024 * 16) return launch<1024, 16>(input, values, indices, rows, e, descending, stream);
-    return launch<1024, 22>(input, values, indices, rows, e, descending, stream);
+    if (E <= 256 * 4) return launch<256, 4, I>(input, values, indices, rows, e, descending, stream);
+    if (E <= 1024 * 4) return launch<1024, 4, I>(input, values, indices, rows, e, descending, stream);
+    if (E <= 1024 * 8) return launch<1024, 8, I>(input, values, indices, rows, e, descending, stream);
+    if (E <= 1024 * 16) return launch<1024, 16, I>(input, values, indices, rows, e, descending, stream);
+    return launch<1024, 22, I>(input, values, indices, rows, e, descending, stream);
+}
+
+// input / values [rows, E] fp32, indices [rows, E] int64; sorted along E. E <= gnnops_sort_rows_max_len().
+extern "C" int gnnops_sort_rows_f32(const float* input, float* values, int64_t* indices, int64_t rows, int64_t E,
+                                    int descending, gnnops_stream_t s) {
+    return sort_rows_any<int64_t>(input, values, indices, rows, E, descending, (hipStream_t)s);
+}
+// The same with the positions as int32 rows, for a caller that widens them itself in a later pass.
+extern "C" int gnnops_sort_rows_f32_i32(const float* input, float* values, int32_t* indices, int64_t rows, int64_t E,
+                                        int descending, gnnops_stream_t s) {
+    return sort_rows_any<int32_t>(input, values, indices, rows, E, descending, (hipStream_t)s);
 }
 
 // Largest row length of the two-half form: the merge keeps one 4-byte order image per key of a row in LDS.
 extern "C" int64_t gnnops_sort_rows2_max_len(void) { return 40000; }
 
-// Rows longer than gnnops_sort_rows_max_len(), up to gnnops_sort_rows2_max_len(): the halves are sorted on chip into (tmp_values,
-// tmp_indices) — each [rows, E], caller-provided — and merged into (values, indices).
-extern "C" int gnnops_sort_rows2_f32(const float* input, float* values, int64_t* indices, float* tmp_values,
-                                     int64_t* tmp_indices, int64_t rows, int64_t E, int descending, gnnops_stream_t s) {
-    hipStream_t stream = (hipStream_t)s;
+template <typename I>
+static int sort_rows2_any(const float* input, float* values, I* indices, float* tmp_values, int32_t* tmp_indices, int64_t rows, int64_t E,
+                          int descending, hipStream_t stream) {
     GNNOPS_REQUIRE(rows >= 0 && E >= 0, GNNOPS_EINVAL, "sort_rows2: negative size");
     GNNOPS_REQUIRE(E > gnnops_sort_rows_max_len() && E <= gnnops_sort_rows2_max_len(), GNNOPS_EUNSUPPORTED,
                    "sort_rows2: row length %lld outside (%lld, %lld]", (long long)E, (long long)gnnops_sort_rows_max_len(),
@@ -269,17 +279,29 @@ extern "C" int gnnops_sort_rows2_f32(const float* input, float* values, int64_t*
     GNNOPS_REQUIRE(input && values && indices && tmp_values && tmp_indices, GNNOPS_EINVAL, "sort_rows2: null pointer");
     const int e = (int)E, h0 = (e + 1) / 2;
     int rc;
-    if (h0 <= 1024 * 16) rc = launch<1024, 16>(input, tmp_values, tmp_indices, rows, e, descending, stream, 2, h0);
-    else rc = launch<1024, 22>(input, tmp_values, tmp_indices, rows, e, descending, stream, 2, h0);
+    if (h0 <= 1024 * 16) rc = launch<1024, 16, int32_t>(input, tmp_values, tmp_indices, rows, e, descending, stream, 2, h0);
+    else rc = launch<1024, 22, int32_t>(input, tmp_values, tmp_indices, rows, e, descending, stream, 2, h0);
     if (rc != GNNOPS_OK) return rc;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_halves_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_halves_kernel<I>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return gnnops_check_launch("sort_rows2 attribute");
         configured = true;
     }
-    hipLaunchKernelGGL(merge_halves_kernel, dim3(gnnops_grid_cap(rows, 256 * 4)), dim3(MERGE_THREADS), (size_t)E * 4, stream,
+    hipLaunchKernelGGL(merge_halves_kernel<I>, dim3(gnnops_grid_cap(rows, 256 * 4)), dim3(MERGE_THREADS), (size_t)E * 4, stream,
                        tmp_values, tmp_indices, values, indices, rows, e, h0, descending);
     return gnnops_check_launch("sort_rows2");
+}
+
+// Rows longer than gnnops_sort_rows_max_len(), up to gnnops_sort_rows2_max_len(): the halves are sorted on chip into (tmp_values,
+// tmp_indices) — each [rows, E], caller-provided — and merged into (values, indices). The half-sorted positions are kept as
+// int32 inside tmp_indices whatever its declared width (the first 4 * rows * E bytes are used).
+extern "C" int gnnops_sort_rows2_f32(const float* input, float* values, int64_t* indices, float* tmp_values,
+                                     int64_t* tmp_indices, int64_t rows, int64_t E, int descending, gnnops_stream_t s) {
+    return sort_rows2_any<int64_t>(input, values, indices, tmp_values, reinterpret_cast<int32_t*>(tmp_indices), rows, E, descending, (hipStream_t)s);
+}
+extern "C" int gnnops_sort_rows2_f32_i32(const float* input, float* values, int32_t* indices, float* tmp_values,
+                                         int32_t* tmp_indices, int64_t rows, int64_t E, int descending, gnnops_stream_t s) {
+    return sort_rows2_any<int32_t>(input, values, indices, tmp_values, tmp_indices, rows, E, descending, (hipStream_t)s);
 }

@@ -63,7 +63,9 @@ SIGNATURES = {
     "gnnops_sort_rows_max_len": (_i64, []),
     "gnnops_sort_rows2_max_len": (_i64, []),
     "gnnops_sort_rows_f32": (_ci, [_vp, _vp, _vp, _i64, _i64, _ci, _vp]),
+    "gnnops_sort_rows_f32_i32": (_ci, [_vp, _vp, _vp, _i64, _i64, _ci, _vp]),
     "gnnops_sort_rows2_f32": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _ci, _vp]),
+    "gnnops_sort_rows2_f32_i32": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _ci, _vp]),
     "gnnops_coalesce_workspace_bytes": (_sz, [_i64]),
     "gnnops_coalesce": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gnnops_transpose2d": (_ci, [_vp, _vp, _i64, _i64, _ci, _vp]),

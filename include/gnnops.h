@@ -282,6 +282,12 @@ int64_t gnnops_sort_rows2_max_len(void);
  * (tmp_values, tmp_indices) — each [rows, E] — then rank-merged into (values, indices). Same ordering conventions. */
 int gnnops_sort_rows2_f32(const float* input, float* values, int64_t* indices, float* tmp_values, int64_t* tmp_indices,
                           int64_t rows, int64_t E, int descending, gnnops_stream_t stream);
+/* Both with the positions as int32 rows (they fit: a row is at most gnnops_sort_rows2_max_len() long), for a caller that widens
+ * them in a later pass of its own (torch.sort along dim 0 of a matrix: gnnops_transpose2d_cvt mode 1 on the way back). */
+int gnnops_sort_rows_f32_i32(const float* input, float* values, int32_t* indices, int64_t rows, int64_t E,
+                             int descending, gnnops_stream_t stream);
+int gnnops_sort_rows2_f32_i32(const float* input, float* values, int32_t* indices, float* tmp_values, int32_t* tmp_indices,
+                              int64_t rows, int64_t E, int descending, gnnops_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch_sparse.coalesce(index, value, m, n, op="add") / Tensor.coalesce()
