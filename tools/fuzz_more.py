@@ -1,0 +1,74 @@
+"""One-off extended fuzz on the GPU box (not part of the suite): the seeded random sweeps of tests/test_random_gpu.py over many more
+seeds, random 16-bit addmm shapes (in-place operands vs whole padded copies bit for bit, split-K vs plain grid within one
+rounding, sampled rows vs float64), random clouds through the grid knn / radius vs the exhaustive kernels.
+usage: fuzz_more.py [first_seed] [count]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "gnn-ops-benchmark_amd"), ROOT, os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import gnnops
+from oracle import oracle
+import test_random_gpu as T
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+gnnops.set_plan_cache(False)
+fails = 0
+t0 = time.time()
+fns = [getattr(T, n) for n in dir(T) if n.startswith("test_random")]
+for seed in range(first, first + count):
+    for fn in fns:
+        try:
+            fn(gnnops, oracle, seed)
+        except Exception as e:      # noqa: BLE001 - report and go on
+            fails += 1
+            print(f"FAIL {fn.__name__} seed={seed}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+    if (seed - first) % 10 == 9:
+        print(f"... random sweeps through seed {seed}, {time.time() - t0:.0f} s, {fails} failures", flush=True)
+
+# ---- addmm shapes
+rng = np.random.default_rng(first)
+g = torch.Generator(device="cuda").manual_seed(first)
+for it in range(count):
+    M = int(rng.integers(512, 6000)); N = int(rng.integers(512, 6000)); K = int(rng.integers(256, 3000))
+    dt = torch.float16 if it % 2 else torch.bfloat16
+    a = (torch.rand(M, K, generator=g, device="cuda") - 0.5).to(dt)
+    b = (torch.rand(K, N, generator=g, device="cuda") - 0.5).to(dt)
+    c = (torch.rand(M, N, generator=g, device="cuda") - 0.5).to(dt)
+    got = gnnops.addmm(c, a, b)
+    os.environ["GNNOPS_GEMM_PAD"] = "full"
+    full = gnnops.addmm(c, a, b)
+    os.environ.pop("GNNOPS_GEMM_PAD")
+    os.environ["GNNOPS_GEMM_SK"] = "0"
+    plain = gnnops.addmm(c, a, b)
+    os.environ.pop("GNNOPS_GEMM_SK")
+    rows = torch.randint(0, M, (16,), device="cuda")
+    ref = c[rows].double() + a[rows].double() @ b.double()
+    err = (got[rows].double() - ref).abs().max().item()
+    ulp = (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * max(1.0, ref.abs().max().item())
+    ok = torch.equal(got, full) and (got.float() - plain.float()).abs().max().item() <= ulp and err <= 2 * ulp + 4 * K * 2.0 ** -24 * 0.25 * K
+    if not ok:
+        fails += 1
+        print(f"FAIL addmm M={M} N={N} K={K} {dt}: equal_full={torch.equal(got, full)} d_plain={(got.float() - plain.float()).abs().max().item():.4g} err64={err:.4g}", flush=True)
+print(f"... addmm shapes done, {time.time() - t0:.0f} s, {fails} failures", flush=True)
+
+# ---- knn / radius clouds
+from torch_cluster import knn, radius
+from gnnops import spatial
+for it in range(count // 2):
+    D = int(rng.integers(1, 4)); n = int(rng.integers(8192, 60000)); k = int(rng.integers(1, 65))
+    kind = it % 3
+    x = torch.rand(n, D, generator=g, device="cuda")
+    if kind == 1: x = (x * 20).floor() / 20
+    if kind == 2: x[: n // 2] = x[: n // 2] * 0.01 + 5.0
+    y = torch.rand(int(rng.integers(10, 400)), D, generator=g, device="cuda") * 1.5 - 0.25
+    r = float(rng.random() * 0.2)
+    a1, b1 = knn(x, y, k), radius(x, y, r, max_num_neighbors=min(k, 64))
+    save = spatial._KNN_GRID_MIN_POINTS
+    spatial._KNN_GRID_MIN_POINTS = 1 << 40
+    a0, b0 = knn(x, y, k), radius(x, y, r, max_num_neighbors=min(k, 64))
+    spatial._KNN_GRID_MIN_POINTS = save
+    if not (torch.equal(a0, a1) and torch.equal(b0, b1)):
+        fails += 1
+        print(f"FAIL knn/radius D={D} n={n} k={k} kind={kind} r={r:.3f}: knn={torch.equal(a0, a1)} radius={torch.equal(b0, b1)}", flush=True)
+print(f"DONE in {time.time() - t0:.0f} s: {fails} failures", flush=True)
