@@ -341,42 +341,133 @@ __global__ __launch_bounds__(256) void radius_kernel(const T* __restrict__ x, co
     }
 }
 
+// Wave-wide maximum of a 64-bit key by DPP moves (row shifts inside the 16-lane rows, then the two row broadcasts): a handful of
+// VALU instructions per step where __shfl_xor is a ds_bpermute round trip (~100 cycles, and a (distance, int64 index) pair is
+// three of them per step) — the farthest-point loop below is ONE dependent reduction per sampled point, so this latency is
+// its running time. 0 is the identity (lanes a move does not reach read 0). Every lane gets the result.
+__device__ inline uint64_t wave_max_u64(uint64_t v) {
+#define GNNOPS_DPP_MAX(CTRL, ROWMASK)                                                                                      \
+    {                                                                                                                      \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWMASK, 0xf, false);         \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWMASK, 0xf, false); \
+        const uint64_t o = ((uint64_t)hi << 32) | lo;                                                                      \
+        v = o > v ? o : v;                                                                                                 \
+    }
+    GNNOPS_DPP_MAX(0x111, 0xf)   // row_shr:1
+    GNNOPS_DPP_MAX(0x112, 0xf)   // row_shr:2
+    GNNOPS_DPP_MAX(0x114, 0xf)   // row_shr:4
+    GNNOPS_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row's maximum
+    GNNOPS_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    GNNOPS_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef GNNOPS_DPP_MAX
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+// (distance, index) -> a key whose maximum is the farthest point, the smaller index among equals (rel = index - segment start);
+// 0 = "no point" loses to every key
+__device__ inline uint64_t fps_key(float d, uint32_t rel) { return ((uint64_t)knn_order(d) << 32) | (0xffffffffu - rel); }
+
 // ---- fps: one workgroup per batch segment; dist[] = squared distance to the nearest chosen point so far ----
+template <typename T, int DD>
+__device__ inline void fps_in_registers(const T* __restrict__ x, int64_t xb, int64_t xe, int64_t ob, int64_t oe, int64_t cur,
+                                        int64_t* __restrict__ out) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    {
+        // A cloud of at most 8192 points in <= 3 dimensions (the sampling layers of point networks): every thread keeps its (up to
+        // eight) points and their running distances in REGISTERS, and the chosen point's coordinates travel through LDS with the
+        // reduction — nothing is read from or written to memory inside the sampling loop but the output index. The general
+        // loop below re-reads dist[] and x[] from L2 and fetches x[cur] anew in every one of the (dependent) iterations.
+        // Only as many waves as give a thread four to eight points (1024 points: four waves, one per SIMD) — the others leave at
+        // once: the loop is one dependent instruction stream per wave, so fewer, shorter streams and fewer waves at the barriers.
+        __shared__ float s_x[16][3];
+        constexpr int PPT = 8;
+        const int per = xe - xb <= 2048 ? 4 : 8;                 // points per thread: four for small clouds, eight above (measured)
+        int nthr = (int)(((xe - xb + per - 1) / per + 63) / 64 * 64);   // 64 .. 1024 threads
+        if (nthr > 1024) nthr = 1024;
+        const int nw = nthr >> 6;
+        if (t >= nthr) return;
+        float px[PPT][3], pd[PPT];
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            const int64_t i = xb + t + (int64_t)p * nthr;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) px[p][d] = (i < xe && d < DD) ? Elem<T>::load(x + i * DD + d) : 0.f;
+            pd[p] = __builtin_huge_valf();
+        }
+        float cx[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) cx[d] = d < DD ? Elem<T>::load(x + cur * DD + d) : 0.f;
+        __shared__ uint64_t s_k[16];
+        for (int64_t m = ob + 1; m < oe; ++m) {
+            uint64_t best = 0;
+            float bx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) {
+                const int64_t i = xb + t + (int64_t)p * nthr;
+                if (i < xe) {
+                    float sq = 0.f;
+                    #pragma unroll
+                    for (int d = 0; d < DD; ++d) {         // the sum of dist2<T>, term by term
+                        const float df = px[p][d] - cx[d];
+                        sq += df * df;
+                    }
+                    const float dd = fminf(pd[p], sq);
+                    pd[p] = dd;
+                    const uint64_t key = fps_key(dd, (uint32_t)(i - xb));
+                    if (key > best) { best = key; bx[0] = px[p][0]; bx[1] = px[p][1]; bx[2] = px[p][2]; }
+                }
+            }
+            const uint64_t wbest = wave_max_u64(best);
+            if (best == wbest && best != 0) { s_x[wave][0] = bx[0]; s_x[wave][1] = bx[1]; s_x[wave][2] = bx[2]; }
+            if (lane == 0) s_k[wave] = wbest;
+            __syncthreads();
+            int win = 0;
+            uint64_t top = s_k[0];
+            for (int w = 1; w < nw; ++w)
+                if (s_k[w] > top) { top = s_k[w]; win = w; }
+            cx[0] = s_x[win][0]; cx[1] = s_x[win][1]; cx[2] = s_x[win][2];
+            __syncthreads();
+            cur = xb + (int64_t)(0xffffffffu - (uint32_t)top);
+            if (t == 0) out[m] = cur;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void fps_kernel(const T* __restrict__ x, const int64_t* __restrict__ ptr, const int64_t* __restrict__ out_ptr,
                                                    const int64_t* __restrict__ start, int D, float* __restrict__ dist,
-                                                   int64_t* __restrict__ out) {
-    __shared__ float s_d[16];
-    __shared__ int64_t s_i[16];
+                                                   int64_t* __restrict__ out, int in_registers) {
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t xb = ptr[b], xe = ptr[b + 1];
     const int64_t ob = out_ptr[b], oe = out_ptr[b + 1];
     if (ob == oe || xb == xe) return;
     int64_t cur = start[b];
     if (t == 0) out[ob] = cur;
+    if (in_registers && D <= 3 && xe - xb <= 8 * 1024) {
+        if (D == 1) fps_in_registers<T, 1>(x, xb, xe, ob, oe, cur, out);
+        else if (D == 2) fps_in_registers<T, 2>(x, xb, xe, ob, oe, cur, out);
+        else fps_in_registers<T, 3>(x, xb, xe, ob, oe, cur, out);
+        return;
+    }
     for (int64_t i = xb + t; i < xe; i += 1024) dist[i] = __builtin_huge_valf();
+    __shared__ uint64_t s_k[16];
     for (int64_t m = ob + 1; m < oe; ++m) {
-        float best_d = -1.f;
-        int64_t best_i = INT64_MAX;
+        uint64_t best = 0;   // fps_key: farthest point, the smaller index among equals (torch.argmax's first maximum)
         for (int64_t i = xb + t; i < xe; i += 1024) {
             const float d = fminf(dist[i], dist2<T>(x + i * D, x + cur * D, D));
             dist[i] = d;
-            if (d > best_d || (d == best_d && i < best_i)) { best_d = d; best_i = i; }
+            const uint64_t key = fps_key(d, (uint32_t)(i - xb));
+            best = key > best ? key : best;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {   // farthest point; ties to the smaller index (torch.argmax's first maximum)
-            const float od = __shfl_xor(best_d, o);
-            const int64_t oi = __shfl_xor(best_i, o);
-            if (od > best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
-        }
-        if (lane == 0) { s_d[wave] = best_d; s_i[wave] = best_i; }
+        const uint64_t wbest = wave_max_u64(best);
+        if (lane == 0) s_k[wave] = wbest;
         __syncthreads();
-        best_d = s_d[0]; best_i = s_i[0];
+        uint64_t top = s_k[0];
 #pragma unroll
-        for (int w = 1; w < 16; ++w)
-            if (s_d[w] > best_d || (s_d[w] == best_d && s_i[w] < best_i)) { best_d = s_d[w]; best_i = s_i[w]; }
+        for (int w = 1; w < 16; ++w) top = s_k[w] > top ? s_k[w] : top;
         __syncthreads();
-        cur = best_i;
+        cur = xb + (int64_t)(0xffffffffu - (uint32_t)top);
         if (t == 0) out[m] = cur;
     }
 }
@@ -602,8 +693,10 @@ extern "C" int gnnops_fps(const void* x, const int64_t* ptr, const int64_t* out_
     GNNOPS_REQUIRE(batches >= 0 && batches < (1 << 30) && D >= 1, GNNOPS_EINVAL, "fps: bad shape");
     if (batches == 0) return GNNOPS_OK;
     GNNOPS_REQUIRE(x && ptr && out_ptr && start && dist_workspace && out, GNNOPS_EINVAL, "fps: null pointer");
+    const char* fr = getenv("GNNOPS_FPS_REGISTERS");   // A/B and tests: 0 = the general loop for every cloud
+    const int in_registers = !(fr && fr[0] == '0');
     GNNOPS_BY_DTYPE(dtype, hipLaunchKernelGGL((fps_kernel<T>), dim3((unsigned)batches), dim3(1024), 0, (hipStream_t)s, (const T*)x, ptr, out_ptr,
-                                              start, D, dist_workspace, out), "fps")
+                                              start, D, dist_workspace, out, in_registers), "fps")
     return gnnops_check_launch("fps");
 }
 

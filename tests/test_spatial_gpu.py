@@ -123,6 +123,26 @@ def test_fps(ora, batches):
         assert torch.equal(torch.bincount(batch[rnd.cpu()], minlength=batches), torch.ceil(torch.bincount(batch, minlength=batches) * 0.25).long())
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("D", [1, 2, 3, 5])
+def test_fps_clouds_kept_in_registers(dt, D, monkeypatch):
+    """Clouds of at most 8192 points in <= 3 dimensions keep their points and running distances in registers (csrc/cluster.hip
+    fps_kernel); GNNOPS_FPS_REGISTERS=0 forces the general loop. The same samples in the same order: ragged clouds (1, 2, 63,
+    1025, 8192 and 8193 points — the last takes the general loop either way), duplicated points (ties to the smaller
+    index), D = 5 (general loop)."""
+    from torch_cluster import fps
+
+    g = torch.Generator().manual_seed(17 + D)
+    sizes = [1, 2, 63, 1025, 8192, 8193, 700]
+    x = torch.cat([torch.rand(n, D, generator=g) for n in sizes]).to(dt)
+    x[70:100] = x[66:67]                         # a run of equal points inside the 1025-point cloud
+    batch = torch.cat([torch.full((n,), b) for b, n in enumerate(sizes)])
+    got = fps(x.cuda(), batch.cuda(), ratio=0.3, random_start=False)
+    monkeypatch.setenv("GNNOPS_FPS_REGISTERS", "0")
+    ref = fps(x.cuda(), batch.cuda(), ratio=0.3, random_start=False)
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("batches,cosine", [(1, False), (4, False), (3, True)])
 def test_knn_and_knn_graph(ora, batches, cosine):
     from torch_cluster import knn, knn_graph
