@@ -114,12 +114,16 @@ __device__ inline uint32_t knn_order(float v) {
     if (u == 0x80000000u) u = 0u;
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// lane `src` (the same in every lane) of a 64-bit value: two v_readlane, no trip through the LDS crossbar
 __device__ inline uint64_t shfl_u64(uint64_t v, int src) {
-    const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
+// the value of the lane below (lane 0 keeps its own): one DPP wave shift per half
 __device__ inline uint64_t shfl_up_u64(uint64_t v) {
-    const uint32_t lo = __shfl_up((uint32_t)v, 1), hi = __shfl_up((uint32_t)(v >> 32), 1);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);          // wave_shr:1
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
     return ((uint64_t)hi << 32) | lo;
 }
 template <typename T, bool COSINE>

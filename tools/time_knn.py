@@ -19,14 +19,18 @@ for n, nb in ((32768, 32), (100000, 1), (400000, 1)):     # 32 clouds of 1024 po
     b = (torch.arange(n, device="cuda") * nb // n)
     for k in (6, 16, 40):
         os.environ.pop("GNNOPS_KNN_ROUNDS", None)
+        spatial._KNN_GRID_MIN_POINTS = 1 << 40            # the exhaustive kernels, also for one large cloud under a batch vector
         t1, o1 = timed(x, x, k, b, b)
         tg = None
         if nb == 1:
+            spatial._KNN_GRID_MIN_POINTS = 8192
             tg, og = timed(x, x, k, None, None, iters=10)
+            spatial._KNN_GRID_MIN_POINTS = 1 << 40
             assert torch.equal(og, o1)
         os.environ["GNNOPS_KNN_ROUNDS"] = "1"
         t0, o0 = timed(x, x, k, b, b)
         os.environ.pop("GNNOPS_KNN_ROUNDS", None)
+        spatial._KNN_GRID_MIN_POINTS = 8192
         print(f"n={n:7d} clouds={nb:3d} k={k:3d}: k rounds {t0:9.3f} ms   one pass {t1:9.3f} ms   ({t0 / t1:5.1f}x)  equal={torch.equal(o0, o1)}" + (f"   grid {tg:8.3f} ms ({t1 / tg:6.1f}x the one pass)" if tg else ""), flush=True)
 for n in (1_000_000, 4_000_000):
     x = torch.rand(n, 3, device="cuda")
