@@ -249,6 +249,8 @@ def _by_cloud(x, y, k, ptr_x, ptr_y, radius, exhaustive):
     B = ptr_x.numel() - 1
     if B < 1 or B > _KNN_GRID_MAX_BATCHES or x.size(0) < _KNN_GRID_MIN_POINTS:
         return None
+    if B > 1 and x.size(0) < B * (_KNN_GRID_MIN_POINTS // 4):
+        return None      # many small clouds (32 x 1024 points): not worth reading the pointers back to find out that none is large
     px, py = ptr_x.tolist(), ptr_y.tolist()
     if not any(px[b + 1] - px[b] >= _KNN_GRID_MIN_POINTS and py[b + 1] > py[b] for b in range(B)):
         return None
