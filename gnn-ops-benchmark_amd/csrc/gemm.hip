@@ -1119,7 +1119,10 @@ int launch_sk256(const void* input, const void* mat1, const void* mat2, void* ou
     if (gnnops_memset_async(flags, 0, sk_flag_bytes(G), stream) != hipSuccess) return gnnops_check_launch("addmm flags");
     const int tiles_m = (int)gnnops_cdiv(M, BM2), tiles_n = (int)gnnops_cdiv(N, BN2);
     const char* od = getenv("GNNOPS_GEMM_SK_ORDER");  // A/B: bit 0 = workgroup id by XCD share, bit 1 = tile ids down bands of 8 rows
-    const int order = od ? atoi(od) : 3;
+    int order = od ? atoi(od) : 3;
+    // bits 4 and 8 (no hand-off / no tail) leave the last round's tiles WRONG: they exist for tools/time_gemm_sk_parts.py, which also
+    // sets GNNOPS_GEMM_SK_TIMING_ONLY — without that they are ignored
+    if (!getenv("GNNOPS_GEMM_SK_TIMING_ONLY")) order &= 3;
     const int tail_tiles = (int)((int64_t)tiles_m * tiles_n % G), dp_tiles = tiles_m * tiles_n - tail_tiles;
     hipLaunchKernelGGL((gemm_sk256_kernel<T, IS_BF16>), dim3((unsigned)G), dim3(512), GEMM256_SMEM, stream, (const uint16_t*)mat1,
                        (const uint16_t*)mat2, (const T*)input, (T*)out, M, N, K, lda, ldb, ldadd, at, bt, Kmain, (float*)sk_ws, flags, tiles_m,
