@@ -57,6 +57,40 @@ for it in range(count):
         print(f"FAIL big-N scatter shape={shape} dim={dim} N={N} {reduce} implicit={bool(it % 2)}", flush=True)
 print(f"... big-N layout-F scatters done, {time.time() - t0:.0f} s, {fails} failures", flush=True)
 
+# ---- sparse family against torch on the CPU: coalesce (index bit-exact, values to a tolerance), spmm, spspmm, sparse transpose
+import torch_sparse
+rng3 = np.random.default_rng(first + 13)
+gs = torch.Generator().manual_seed(first + 13)
+for it in range(count):
+    m = int(rng3.integers(1, 3000)); n = int(rng3.integers(1, 3000)); nnz = int(rng3.integers(0, 60000)); D = int(rng3.choice([1, 3, 16, 64, 100]))
+    row = torch.randint(0, m, (nnz,), generator=gs); col = torch.randint(0, n, (nnz,), generator=gs)
+    val = torch.rand(nnz, generator=gs) - 0.5
+    idx = torch.stack([row, col])
+    try:
+        ci, cv = torch_sparse.coalesce(idx.cuda(), val.cuda(), m, n)
+        ref = torch.sparse_coo_tensor(idx, val, (m, n)).coalesce()
+        ok = torch.equal(ci.cpu(), ref.indices()) and torch.allclose(cv.cpu(), ref.values(), rtol=1e-5, atol=1e-6)
+        dense = torch.rand(n, D, generator=gs) - 0.5
+        out = torch_sparse.spmm(idx.cuda(), val.cuda(), m, n, dense.cuda())
+        ok = ok and torch.allclose(out.cpu(), torch.sparse.mm(ref, dense), rtol=1e-4, atol=1e-5)
+        ti, tv = torch_sparse.transpose(ci, cv, m, n)
+        rt = ref.t().coalesce()
+        ok = ok and torch.equal(ti.cpu(), rt.indices()) and torch.allclose(tv.cpu(), rt.values(), rtol=1e-5, atol=1e-6)
+        if it % 4 == 0 and nnz < 20000:
+            k2 = int(rng3.integers(1, 2000)); nnz2 = int(rng3.integers(0, 20000))
+            r2 = torch.randint(0, n, (nnz2,), generator=gs); c2 = torch.randint(0, k2, (nnz2,), generator=gs); v2 = torch.rand(nnz2, generator=gs) - 0.5
+            pi, pv = torch_sparse.spspmm(idx.cuda(), val.cuda(), torch.stack([r2, c2]).cuda(), v2.cuda(), m, n, k2)
+            rp = torch.sparse.mm(ref, torch.sparse_coo_tensor(torch.stack([r2, c2]), v2, (n, k2)).coalesce()).coalesce()
+            got = torch.sparse_coo_tensor(pi.cpu(), pv.cpu(), (m, k2)).coalesce()
+            ok = ok and torch.allclose(got.to_dense(), rp.to_dense(), rtol=1e-4, atol=1e-5) and bool((pi.cpu()[0][1:] * k2 + pi.cpu()[1][1:] > pi.cpu()[0][:-1] * k2 + pi.cpu()[1][:-1]).all())
+    except Exception as e:      # noqa: BLE001
+        ok = False
+        print(f"   {type(e).__name__}: {str(e)[:200]}")
+    if not ok:
+        fails += 1
+        print(f"FAIL sparse m={m} n={n} nnz={nnz} D={D}", flush=True)
+print(f"... sparse family done, {time.time() - t0:.0f} s, {fails} failures", flush=True)
+
 # ---- addmm shapes
 rng = np.random.default_rng(first)
 g = torch.Generator(device="cuda").manual_seed(first)
