@@ -1797,7 +1797,6 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
         // 16-B piece may run into the next row, and behind B's very last row there is no next row), or copied whole into
         // aligned zero-padded rows. GNNOPS_GEMM_PAD = full | a | b | none forces a choice (tools/time_gemm_pad.py).
         const bool need = K % 64 != 0 || N % 8 != 0;
-        const bool misaligned = K % 8 != 0 || N % 8 != 0;
         const char* pd = getenv("GNNOPS_GEMM_PAD");
         bool whole_a = false, whole_b = false;
         if (pd && pd[0] == 'f') whole_a = whole_b = true;
@@ -1817,7 +1816,6 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K) {
         g.b_bytes = g.copy_b ? align_up((size_t)g.Kp * g.ldb * 2, 256) : 0;
         g.at_bytes = g.tail_a ? align_up((size_t)M * 64 * 2, 256) : 0;
         g.bt_bytes = g.tail_b ? align_up(((size_t)64 * N + 8) * 2, 256) : 0;
-        (void)misaligned;
         if (g.path == 2) {
             g.sk_split = sk_split_of(gnnops_cdiv(M, BM2) * gnnops_cdiv(N, BN2), cu_count());
             g.sk_bytes = g.sk_split > 1 ? sk_workspace_bytes(cu_count()) : 0;
