@@ -13,6 +13,17 @@ for sw in ("0", "3", "1"):  # 0 = default ladder (256 x 256 ping-pong at this si
     for _ in range(3):
         out = gnnops.addmm(c, a, b)
 os.environ["GNNOPS_GEMM_NO_DMA"] = "0"
+# round 3: 17 x 17 tiles (a last round of 33: the persistent split-K kernel) beside the plain grid on the same operands, and the
+# reference's largest fp16 length (operands in place / A copied)
+for L2, dt2 in ((4352, torch.bfloat16), (8164, torch.float16)):
+    a2, b2, c2 = [(torch.rand(L2, L2, generator=g, device="cuda") * 2 - 1).to(dt2) for _ in range(3)]
+    for sk in ("", "0"):
+        if sk: os.environ["GNNOPS_GEMM_SK"] = sk
+        else: os.environ.pop("GNNOPS_GEMM_SK", None)
+        for _ in range(3):
+            out = gnnops.addmm(c2, a2, b2)
+    os.environ.pop("GNNOPS_GEMM_SK", None)
+    del a2, b2, c2
 a32, b32, c32 = [torch.rand(L, L, generator=g, device="cuda") * 2 - 1 for _ in range(3)]
 for _ in range(3):
     out = gnnops.addmm(c32, a32, b32)   # gemm_f32_kernel
